@@ -1,0 +1,132 @@
+/*
+ * libpygpr_hip -- C ABI of the MI355X (gfx950) dense Gaussian-process hot path.
+ *
+ * The reference (sarath-srinivas/PyGPR, pure Python on torch CPU) has no FFI: its boundary for this
+ * path is the Python class surface, and every entry point below replaces the torch/LAPACK call (or the
+ * Python expression) cited next to it.  pygpr_amd/_lib.py binds these with ctypes; INTEGRATION.md
+ * shows the same stub as a maintainer of the reference would add it.
+ *
+ * Conventions
+ *   - every matrix/vector pointer is a DEVICE pointer owned by the caller (torch-ROCm allocations);
+ *     the library allocates nothing but the streams/events inside a pg_handle
+ *   - matrices are row-major with a leading dimension in elements; dtype is PG_F64 or PG_F32
+ *   - the O(n^3) entry points need n_pad % 256 == 0; pg_kernel_build fills the padding with identity
+ *     (symmetric build) or zeros (cross build), so padded factors are block-diag(L, I)
+ *   - calls are asynchronous on `stream`; return 0 = enqueued, <0 = bad argument / HIP error
+ *     (text via pg_last_error()); numerical failure (non-PD pivot) is reported LAPACK-style in a
+ *     device int `info` that the caller reads after synchronising
+ *   - `hp` is the PyGPR hyper-parameter vector (fp64, device) in Compose order (covar.py:50-55);
+ *     pg_covspec says where each child's parameters sit in it
+ */
+#ifndef PYGPR_HIP_H
+#define PYGPR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_F64 0
+#define PG_F32 1
+#define PG_KIND_RBF 0      /* Squared_exponential, covar.py:84-206 */
+#define PG_KIND_MATERN52 1 /* new (not in the reference), same hp layout */
+#define PG_MAX_COMP 4
+#define PG_MAX_DIM 64
+
+typedef struct pg_ctx* pg_handle;
+
+/* A Compose([...]) of up to PG_MAX_COMP stationary kernels plus white-noise terms (covar.py:28-81). */
+typedef struct pg_covspec {
+    int ncomp;                  /* stationary components                                     */
+    int kind[PG_MAX_COMP];      /* PG_KIND_*                                                 */
+    int off[PG_MAX_COMP];       /* index of [sigma, l_1..l_d] of component c inside hp       */
+    int nnoise;                 /* White_noise children (covar.py:209-269)                   */
+    int noise_off[PG_MAX_COMP]; /* index of each sigma_n inside hp                           */
+} pg_covspec;
+
+int pg_version(void);
+const char* pg_last_error(void);
+int pg_create(pg_handle* h);
+int pg_destroy(pg_handle h);
+
+/* Covariance assembly.  Replaces Compose/Squared_exponential/White_noise.kernel (covar.py:50-62,
+ * 129-167, 227-245).  Xc == NULL: symmetric build on Xr (K[i][j], i,j < nr; diagonal gets
+ * sum(sigma_n^2) + jitter as in gpr.py:68 / loss.py:38); lower_only skips tiles above the diagonal.
+ * Otherwise a cross build K[i][j] = k(Xr_i, Xc_j) (covar.py:152-161; no noise term, covar.py:243). */
+int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* Xr, long ldr,
+                    int nr, const void* Xc, long ldc, int nc, int d, int lower_only, double jitter, void* K,
+                    long ldk, int rows_pad, int cols_pad, void* stream);
+
+/* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag receives the
+ * inverses of the 256x256 diagonal blocks ([n/256][256][256]); they drive every later solve. */
+long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
+int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
+
+/* alpha = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is overwritten
+ * (work vector), x receives the solution; both length n. */
+int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* y, void* x,
+                 void* stream);
+
+/* Minv = L^-1 (lower; its strictly upper blocks are scratch).  First half of cholesky_solve against a
+ * matrix right-hand side (gpr.py:100,112; loss.py:116). */
+int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Minv, long ldm,
+             void* stream);
+
+/* Kinv(lower triangle) = Minv^T Minv = K^-1: what loss.py:116 obtains column by column with
+ * cholesky_solve(dkrn, L). */
+int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Kinv, long ldk, void* stream);
+
+/* y = op(Minv) x for the lower-triangular Minv (trans: 0 = Minv x, 1 = Minv^T x); work: n/256*n elems */
+int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y,
+            void* work, void* stream);
+
+/* out[0] = 1/2 y^T alpha + sum_i log L_ii + n/2 log 2pi   (loss.py:47-49, 107-109); n = real points */
+int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const void* y, const void* alpha,
+                  double* out, void* stream);
+
+/* grad[k] = 1/2 sum (Kinv - alpha alpha^T) o dK/dtheta_k  == -1/2 (tr1 - tr2) of loss.py:116-121 */
+long pg_nlml_grad_worksize(int n, int nhp); /* doubles */
+int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n,
+                 int d, const void* Kinv, long ldk, const void* alpha, double* grad, int nhp, double* work,
+                 long lwork, void* stream);
+
+/* Predictive mean and variance from Ks[n_pad x m_pad] = k(X, Xp) (train rows, test columns):
+ *   mean[j] = sum_i Ks[i][j] alpha[i]                 (gpr.py:80-85)
+ *   q[j]    = sum_i (Minv Ks)[i][j]^2                 (gpr.py:100-104: rowsum(K* o (K^-1 K*^T)^T))
+ * the caller forms var = k** - q (gpr.py:98,102).  work: (n_pad/64) * m_pad elements. */
+int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv,
+                      long ldm, const void* alpha, void* mean, void* q, void* work, void* stream);
+
+/* Dense product V = Minv Ks written out (needed for the full predictive covariance, gpr.py:108-120),
+ * and C = C - V^T V on m_pad x m_pad (lower tiles). */
+int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks,
+                  long ldks, void* V, long ldv, void* stream);
+int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc,
+                   void* stream);
+
+/* Per-expert grBCM terms (gr_bcm.py:125-144): out[0..2][j] = beta, beta*prec, beta*prec*mean with
+ * beta = 1/2 (log prec_c - log prec_g), or 1 when is_first (gr_bcm.py:132); accumulate != 0 adds. */
+int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
+                         int is_first, int accumulate, double* out, long ldo, void* stream);
+/* Finish the committee (gr_bcm.py:133,143,144) from the summed terms and the global expert. */
+int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g,
+                    const void* var_g, void* mean, void* var, void* stream);
+
+/* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
+int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
+
+/* GEMM-core profiling for bench.py's roofline leg: events around every MFMA GEMM launch */
+int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
+int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
+
+/* raw MFMA GEMM core, exposed for tests and the roofline micro-benchmark:
+ * variant 0: C = a A B^T + b C (128x128 tiles; tri != 0 -> lower tiles only), 2: C = a A B + b C,
+ * 3: C = a A^T B + b C.  klo/khi as in csrc/gemm.h. */
+int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,
+                const void* B, long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,96 @@
+"""ctypes binding of libpygpr_hip.so (C ABI: include/pygpr_hip.h).
+
+There is no CPU fallback: `load()` raises if the shared object is missing, and every compute call
+needs a HIP device.  Build the library with `python __graft_entry__.py` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpygpr_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pygpr_hip.h")
+
+PG_F64, PG_F32 = 0, 1
+PG_KIND_RBF, PG_KIND_MATERN52 = 0, 1
+PG_MAX_COMP, PG_MAX_DIM = 4, 64
+PAD = 256  # every dimension given to the O(n^3) entry points is a multiple of this
+
+GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3, 5
+
+
+class CovSpec(C.Structure):
+    _fields_ = [
+        ("ncomp", C.c_int),
+        ("kind", C.c_int * PG_MAX_COMP),
+        ("off", C.c_int * PG_MAX_COMP),
+        ("nnoise", C.c_int),
+        ("noise_off", C.c_int * PG_MAX_COMP),
+    ]
+
+
+_vp, _i, _l, _d = C.c_void_p, C.c_int, C.c_long, C.c_double
+_SIGS = {
+    "pg_version": (C.c_int, []),
+    "pg_last_error": (C.c_char_p, []),
+    "pg_create": (_i, [C.POINTER(_vp)]),
+    "pg_destroy": (_i, [_vp]),
+    "pg_kernel_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _vp, _l, _i, _i, _i, _d, _vp, _l, _i, _i, _vp]),
+    "pg_potrf_worksize": (_l, [_i, _i]),
+    "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
+    "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "pg_trtri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
+    "pg_lauum": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "pg_trmv": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp]),
+    "pg_nlml_value": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "pg_nlml_grad_worksize": (_l, [_i, _i]),
+    "pg_nlml_grad": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
+    "pg_predict_mean_q": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "pg_trmm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp]),
+    "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
+    "pg_profile": (_i, [_vp, _i]),
+    "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
+    "pg_gemm_raw": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _l, _vp, _l, _d, _vp, _l, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Names of every function declared in include/pygpr_hip.h."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z_0-9]+)\s*\(", text)))
+
+
+def load(check_symbols=False):
+    """dlopen the library (no GPU needed for that) and attach the prototypes."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpygpr_hip.so not found at %s -- the HIP extension is required (no CPU fallback); "
+                "build it with `python __graft_entry__.py`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    if check_symbols:
+        missing = [s for s in header_symbols() if not hasattr(_lib, s)]
+        unbound = [s for s in header_symbols() if s not in _SIGS]
+        if missing or unbound:
+            raise RuntimeError("C ABI mismatch: missing in .so %s, unbound in _lib.py %s" % (missing, unbound))
+    return _lib
+
+
+def last_error():
+    return load().pg_last_error().decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libpygpr_hip %s failed (rc=%d): %s" % (what, rc, last_error()))

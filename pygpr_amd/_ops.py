@@ -1,0 +1,190 @@
+"""Device-op layer: torch-ROCm tensors are only buffers + the current stream; every number is
+produced by libpygpr_hip through the C ABI (include/pygpr_hip.h).  No CPU path exists here:
+`get_ops()` raises when the library or a GPU is missing."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import PAD, PG_F32, PG_F64, CovSpec
+
+JITTER = 1e-7  # PyGPR/gpr.py:68, loss.py:38,63,96
+
+
+def pad_to(n, q=PAD):
+    return ((int(n) + q - 1) // q) * q
+
+
+def _code(dtype):
+    if dtype == torch.float64:
+        return PG_F64
+    if dtype == torch.float32:
+        return PG_F32
+    raise TypeError("pygpr_amd computes in float64 or float32, got %s" % dtype)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HipOps:
+    """One per process (one process per GPU)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("pygpr_amd needs a HIP device (MI355X); there is no CPU fallback")
+        h = C.c_void_p()
+        _lib.check(self.lib.pg_create(C.byref(h)), "pg_create")
+        self.h = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _chk(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("device op needs contiguous CUDA tensors")
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t, dtype=None):
+        return t.detach().to(device=self.device, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+    # -- covariance assembly ------------------------------------------------------------------
+    def kernel_build(self, spec, hp, xr, xc, out, lower_only=False, jitter=0.0):
+        """out[rows_pad, cols_pad] <- k(xr, xc) (xc None: symmetric + noise/jitter diagonal)."""
+        self._chk(hp, xr, xc, out)
+        assert hp.dtype == torch.float64
+        nr, d = xr.shape
+        nc = xc.shape[0] if xc is not None else nr
+        _lib.check(self.lib.pg_kernel_build(
+            self.h, _code(out.dtype), C.byref(spec), _p(hp), _p(xr), xr.stride(0), nr,
+            _p(xc), xc.stride(0) if xc is not None else 0, nc, d, int(lower_only), float(jitter),
+            _p(out), out.stride(0), out.shape[0], out.shape[1], self._st()), "pg_kernel_build")
+        return out
+
+    # -- factorisation and solves -------------------------------------------------------------
+    def potrf_workspace(self, n_pad, dtype):
+        return self.empty(self.lib.pg_potrf_worksize(_code(dtype), n_pad), dtype=dtype)
+
+    def potrf(self, a, invd, info):
+        self._chk(a, invd, info)
+        _lib.check(self.lib.pg_potrf(self.h, _code(a.dtype), a.shape[0], _p(a), a.stride(0), _p(invd), _p(info),
+                                     self._st()), "pg_potrf")
+
+    def potrs_vec(self, chol, invd, y, x):
+        self._chk(chol, invd, y, x)
+        _lib.check(self.lib.pg_potrs_vec(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
+                                         _p(y), _p(x), self._st()), "pg_potrs_vec")
+
+    def trtri(self, chol, invd, minv):
+        self._chk(chol, invd, minv)
+        _lib.check(self.lib.pg_trtri(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
+                                     _p(minv), minv.stride(0), self._st()), "pg_trtri")
+
+    def lauum(self, minv, kinv):
+        self._chk(minv, kinv)
+        _lib.check(self.lib.pg_lauum(self.h, _code(minv.dtype), minv.shape[0], _p(minv), minv.stride(0), _p(kinv),
+                                     kinv.stride(0), self._st()), "pg_lauum")
+
+    def trmv(self, minv, x, y, trans, work=None):
+        self._chk(minv, x, y, work)
+        _lib.check(self.lib.pg_trmv(self.h, _code(minv.dtype), minv.shape[0], _p(minv), minv.stride(0), int(trans),
+                                    _p(x), _p(y), _p(work), self._st()), "pg_trmv")
+
+    def tril(self, a, n):
+        self._chk(a)
+        _lib.check(self.lib.pg_tril(self.h, _code(a.dtype), n, _p(a), a.stride(0), self._st()), "pg_tril")
+
+    # -- NLML ---------------------------------------------------------------------------------
+    def nlml_value(self, chol, y, alpha, n, out):
+        self._chk(chol, y, alpha, out)
+        _lib.check(self.lib.pg_nlml_value(self.h, _code(chol.dtype), n, _p(chol), chol.stride(0), _p(y), _p(alpha),
+                                          _p(out), self._st()), "pg_nlml_value")
+
+    def nlml_grad_worksize(self, n, nhp):
+        return self.lib.pg_nlml_grad_worksize(n, nhp)
+
+    def nlml_grad(self, spec, hp, x, n, kinv, alpha, grad, work):
+        self._chk(hp, x, kinv, alpha, grad, work)
+        _lib.check(self.lib.pg_nlml_grad(self.h, _code(kinv.dtype), C.byref(spec), _p(hp), _p(x), x.stride(0), n,
+                                         x.shape[1], _p(kinv), kinv.stride(0), _p(alpha), _p(grad), grad.numel(),
+                                         _p(work), work.numel(), self._st()), "pg_nlml_grad")
+
+    # -- prediction ---------------------------------------------------------------------------
+    def predict_mean_q(self, ks, minv, alpha, mean, q, work):
+        self._chk(ks, minv, alpha, mean, q, work)
+        _lib.check(self.lib.pg_predict_mean_q(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(ks), ks.stride(0),
+                                              _p(minv), minv.stride(0) if minv is not None else 0, _p(alpha),
+                                              _p(mean), _p(q), _p(work), self._st()), "pg_predict_mean_q")
+
+    def trmm_lower(self, minv, ks, v):
+        self._chk(minv, ks, v)
+        _lib.check(self.lib.pg_trmm_lower(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(minv), minv.stride(0),
+                                          _p(ks), ks.stride(0), _p(v), v.stride(0), self._st()), "pg_trmm_lower")
+
+    def syrk_tn_sub(self, v, c):
+        self._chk(v, c)
+        _lib.check(self.lib.pg_syrk_tn_sub(self.h, _code(v.dtype), c.shape[0], v.shape[0], _p(v), v.stride(0), _p(c),
+                                           c.stride(0), self._st()), "pg_syrk_tn_sub")
+
+    # -- grBCM --------------------------------------------------------------------------------
+    def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out):
+        self._chk(mean_c, var_c, var_g, out)
+        assert out.dtype == torch.float64 and out.shape[0] == 3
+        _lib.check(self.lib.pg_grbcm_local_terms(self.h, _code(mean_c.dtype), mean_c.numel(), _p(mean_c), _p(var_c),
+                                                 _p(var_g), int(is_first), int(accumulate), _p(out), out.stride(0),
+                                                 self._st()), "pg_grbcm_local_terms")
+
+    def grbcm_finish(self, sums, mean_g, var_g, mean, var):
+        self._chk(sums, mean_g, var_g, mean, var)
+        _lib.check(self.lib.pg_grbcm_finish(self.h, _code(mean_g.dtype), mean_g.numel(), _p(sums), sums.stride(0),
+                                            _p(mean_g), _p(var_g), _p(mean), _p(var), self._st()), "pg_grbcm_finish")
+
+    # -- raw GEMM core (tests, roofline micro-benchmark) ---------------------------------------
+    def gemm_raw(self, variant, m, n, k, alpha, a, b, beta, c, tri=0, klo=0, khi=0):
+        self._chk(a, b, c)
+        _lib.check(self.lib.pg_gemm_raw(self.h, _code(c.dtype), variant, m, n, k, float(alpha), _p(a), a.stride(0),
+                                        _p(b), b.stride(0), float(beta), _p(c), c.stride(0), tri, klo, khi,
+                                        self._st()), "pg_gemm_raw")
+
+    def profile(self, on):
+        _lib.check(self.lib.pg_profile(self.h, int(on)), "pg_profile")
+
+    def profile_read(self):
+        f, ms, n = C.c_double(), C.c_double(), C.c_long()
+        _lib.check(self.lib.pg_profile_read(self.h, C.byref(f), C.byref(ms), C.byref(n)), "pg_profile_read")
+        return f.value, ms.value, n.value
+
+
+_OPS = None
+
+
+def get_ops():
+    """The process-wide device-op object; raises (never falls back) without library + GPU."""
+    global _OPS
+    if _OPS is None:
+        _OPS = HipOps()
+    return _OPS
+
+
+def make_spec(kinds, offs, noise_offs):
+    s = CovSpec()
+    if len(kinds) > _lib.PG_MAX_COMP or len(noise_offs) > _lib.PG_MAX_COMP:
+        raise ValueError("a Compose may hold at most %d stationary and %d noise kernels" % (_lib.PG_MAX_COMP, _lib.PG_MAX_COMP))
+    s.ncomp = len(kinds)
+    for i, (k, o) in enumerate(zip(kinds, offs)):
+        s.kind[i], s.off[i] = k, o
+    s.nnoise = len(noise_offs)
+    for i, o in enumerate(noise_offs):
+        s.noise_off[i] = o
+    return s

@@ -1,0 +1,247 @@
+// extern "C" surface of libpygpr_hip (declared in include/pygpr_hip.h): argument checks, dtype dispatch.
+#include "gemm.h"
+#include "kbuild.h"
+#include "linalg.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void pg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define NEED(cond, what)                                         \
+    do {                                                         \
+        if (!(cond)) { pg_set_error("%s: %s", __func__, what); return -1; } \
+    } while (0)
+#define DISPATCH(dtype, CALL_D, CALL_F)                                      \
+    do {                                                                     \
+        if ((dtype) == PG_F64) return CALL_D;                                \
+        if ((dtype) == PG_F32) return CALL_F;                                \
+        pg_set_error("%s: unknown dtype %d", __func__, (int)(dtype));        \
+        return -1;                                                           \
+    } while (0)
+
+template <typename T>
+static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alpha, const void* A, long lda, const void* B,
+                      long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream) {
+    GemmP<T> p;
+    p.A = (const T*)A; p.B = (const T*)B; p.C = (T*)C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = (T)alpha; p.beta = (T)beta;
+    p.tri = tri; p.klo = klo; p.khi = khi;
+    p.sA = p.sB = p.sC = 0; p.batch = 1;
+    p.part = nullptr; p.ldp = 0; p.info = nullptr;
+    return pg_gemm<T>(h, ST(stream), variant, p);
+}
+
+extern "C" {
+
+int pg_version(void) { return 100; }
+const char* pg_last_error(void) { return g_err; }
+
+int pg_create(pg_handle* h) {
+    NEED(h, "null handle pointer");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        pg_set_error("pg_create: no HIP device visible");
+        return -101;
+    }
+    pg_ctx* c = new pg_ctx();
+    memset(c, 0, sizeof(*c));
+    PG_CHECK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
+    *h = c;
+    return 0;
+}
+
+int pg_destroy(pg_handle h) {
+    if (!h) return 0;
+    (void)hipStreamDestroy(h->aux);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+    return 0;
+}
+
+static int check_spec(const pg_covspec* s, const char* fn) {
+    if (!s || s->ncomp < 0 || s->ncomp > PG_MAX_COMP || s->nnoise < 0 || s->nnoise > PG_MAX_COMP) {
+        pg_set_error("%s: bad covariance spec", fn);
+        return -1;
+    }
+    for (int c = 0; c < s->ncomp; ++c)
+        if (s->kind[c] != PG_KIND_RBF && s->kind[c] != PG_KIND_MATERN52) {
+            pg_set_error("%s: unknown kernel kind %d", fn, s->kind[c]);
+            return -1;
+        }
+    return 0;
+}
+
+int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* Xr, long ldr, int nr,
+                    const void* Xc, long ldc, int nc, int d, int lower_only, double jitter, void* K, long ldk,
+                    int rows_pad, int cols_pad, void* stream) {
+    NEED(h && hp && Xr && K, "null pointer");
+    if (check_spec(spec, __func__)) return -1;
+    const int sym = (Xc == nullptr);
+    if (sym) { Xc = Xr; ldc = ldr; nc = nr; }
+    NEED(nr >= 0 && nc >= 0 && rows_pad >= nr && cols_pad >= nc && ldk >= cols_pad, "inconsistent sizes");
+    NEED(!sym || rows_pad == cols_pad, "symmetric build needs a square padded shape");
+    NEED(ldk % (dtype == PG_F64 ? 2 : 4) == 0, "ldk must keep rows 16-byte aligned");
+    DISPATCH(dtype,
+             pg_kbuild<double>(ST(stream), *spec, hp, (const double*)Xr, ldr, nr, (const double*)Xc, ldc, nc, d, sym,
+                               lower_only, jitter, (double*)K, ldk, rows_pad, cols_pad),
+             pg_kbuild<float>(ST(stream), *spec, hp, (const float*)Xr, ldr, nr, (const float*)Xc, ldc, nc, d, sym,
+                              lower_only, jitter, (float*)K, ldk, rows_pad, cols_pad));
+}
+
+long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize_impl(n); }
+
+int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
+    NEED(h && A && inv_diag && info, "null pointer");
+    NEED(lda >= n, "lda < n");
+    DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info),
+             pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info));
+}
+
+int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* y, void* x,
+                 void* stream) {
+    NEED(h && L && inv_diag && y && x, "null pointer");
+    DISPATCH(dtype,
+             pg_potrs_vec_t<double>(h, ST(stream), n, (const double*)L, ldl, (const double*)inv_diag, (const double*)y,
+                                    (double*)x),
+             pg_potrs_vec_t<float>(h, ST(stream), n, (const float*)L, ldl, (const float*)inv_diag, (const float*)y,
+                                   (float*)x));
+}
+
+int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Minv, long ldm,
+             void* stream) {
+    NEED(h && L && inv_diag && Minv, "null pointer");
+    NEED(L != Minv, "pg_trtri is out of place");
+    DISPATCH(dtype,
+             pg_trtri_t<double>(h, ST(stream), n, (const double*)L, ldl, (const double*)inv_diag, (double*)Minv, ldm),
+             pg_trtri_t<float>(h, ST(stream), n, (const float*)L, ldl, (const float*)inv_diag, (float*)Minv, ldm));
+}
+
+int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Kinv, long ldk, void* stream) {
+    NEED(h && Minv && Kinv, "null pointer");
+    NEED(Minv != Kinv, "pg_lauum is out of place");
+    DISPATCH(dtype, pg_lauum_t<double>(h, ST(stream), n, (const double*)Minv, ldm, (double*)Kinv, ldk),
+             pg_lauum_t<float>(h, ST(stream), n, (const float*)Minv, ldm, (float*)Kinv, ldk));
+}
+
+int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y, void* work,
+            void* stream) {
+    NEED(h && Minv && x && y, "null pointer");
+    NEED(!trans || work, "transposed product needs a workspace");
+    NEED(x != y, "pg_trmv is out of place");
+    DISPATCH(dtype,
+             pg_trmv_t<double>(h, ST(stream), n, (const double*)Minv, ldm, trans, (const double*)x, (double*)y, (double*)work),
+             pg_trmv_t<float>(h, ST(stream), n, (const float*)Minv, ldm, trans, (const float*)x, (float*)y, (float*)work));
+}
+
+int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const void* y, const void* alpha, double* out,
+                  void* stream) {
+    NEED(h && L && y && alpha && out, "null pointer");
+    DISPATCH(dtype,
+             pg_nlml_value_t<double>(ST(stream), n, (const double*)L, ldl, (const double*)y, (const double*)alpha, out),
+             pg_nlml_value_t<float>(ST(stream), n, (const float*)L, ldl, (const float*)y, (const float*)alpha, out));
+}
+
+long pg_nlml_grad_worksize(int n, int nhp) { return pg_nlml_grad_worksize_impl(n, nhp); }
+
+int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
+                 const void* Kinv, long ldk, const void* alpha, double* grad, int nhp, double* work, long lwork,
+                 void* stream) {
+    NEED(h && hp && X && Kinv && alpha && grad && work, "null pointer");
+    if (check_spec(spec, __func__)) return -1;
+    DISPATCH(dtype,
+             pg_nlml_grad_t<double>(ST(stream), *spec, hp, (const double*)X, ldx, n, d, (const double*)Kinv, ldk,
+                                    (const double*)alpha, grad, nhp, work, lwork),
+             pg_nlml_grad_t<float>(ST(stream), *spec, hp, (const float*)X, ldx, n, d, (const float*)Kinv, ldk,
+                                   (const float*)alpha, grad, nhp, work, lwork));
+}
+
+int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv, long ldm,
+                      const void* alpha, void* mean, void* q, void* work, void* stream) {
+    NEED(h && Ks && alpha && mean && work, "null pointer");
+    NEED(!q || Minv, "variance needs Minv");
+    DISPATCH(dtype,
+             pg_predict_mean_q_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Ks, ldks, (const double*)Minv, ldm,
+                                         (const double*)alpha, (double*)mean, (double*)q, (double*)work),
+             pg_predict_mean_q_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Ks, ldks, (const float*)Minv, ldm,
+                                        (const float*)alpha, (float*)mean, (float*)q, (float*)work));
+}
+
+int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks, long ldks,
+                  void* V, long ldv, void* stream) {
+    NEED(h && Minv && Ks && V, "null pointer");
+    DISPATCH(dtype,
+             pg_trmm_lower_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Minv, ldm, (const double*)Ks, ldks,
+                                     (double*)V, ldv),
+             pg_trmm_lower_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Minv, ldm, (const float*)Ks, ldks,
+                                    (float*)V, ldv));
+}
+
+int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc, void* stream) {
+    NEED(h && V && C, "null pointer");
+    DISPATCH(dtype, pg_syrk_tn_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)V, ldv, (double*)C, ldc),
+             pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc));
+}
+
+int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
+                         int is_first, int accumulate, double* out, long ldo, void* stream) {
+    NEED(h && mean_c && var_c && var_g && out, "null pointer");
+    NEED(ldo >= m, "ldo < m");
+    DISPATCH(dtype,
+             pg_grbcm_terms_t<double>(ST(stream), m, (const double*)mean_c, (const double*)var_c, (const double*)var_g,
+                                      is_first, accumulate, out, ldo),
+             pg_grbcm_terms_t<float>(ST(stream), m, (const float*)mean_c, (const float*)var_c, (const float*)var_g,
+                                     is_first, accumulate, out, ldo));
+}
+
+int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
+                    void* mean, void* var, void* stream) {
+    NEED(h && sums && mean_g && var_g && mean && var, "null pointer");
+    DISPATCH(dtype,
+             pg_grbcm_finish_t<double>(ST(stream), m, sums, lds, (const double*)mean_g, (const double*)var_g, (double*)mean,
+                                       (double*)var),
+             pg_grbcm_finish_t<float>(ST(stream), m, sums, lds, (const float*)mean_g, (const float*)var_g, (float*)mean,
+                                      (float*)var));
+}
+
+int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
+    NEED(h && A, "null pointer");
+    DISPATCH(dtype, pg_tril_t<double>(ST(stream), n, (double*)A, lda), pg_tril_t<float>(ST(stream), n, (float*)A, lda));
+}
+
+int pg_profile(pg_handle h, int on) {
+    NEED(h, "null handle");
+    if (on) { h->prof_flops = 0; h->prof_ms = 0; h->prof_launches = 0; }
+    h->prof_on = on;
+    return 0;
+}
+int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
+    NEED(h, "null handle");
+    if (flops) *flops = h->prof_flops;
+    if (ms) *ms = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    return 0;
+}
+
+int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,
+                const void* B, long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream) {
+    NEED(h && A && B && C, "null pointer");
+    NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
+             variant == GEMM_TT_128,
+         "variant not exposed");
+    DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),
+             gemm_raw_t<float>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Shared device/host helpers for libpygpr_hip (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "pygpr_hip.h"
+
+#define PG_TILE 128      // GEMM block tile and Cholesky leaf size
+#define PG_PAD 256       // every matrix dimension handed to the O(n^3) kernels is a multiple of this
+
+
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+typedef float pg_f4 __attribute__((ext_vector_type(4)));
+
+struct pg_ctx {
+    hipStream_t aux;          // look-ahead / panel stream
+    hipEvent_t ev[8];
+    int prof_on;              // profiling of the GEMM core (bench roofline leg)
+    double prof_flops;
+    double prof_ms;
+    long prof_launches;
+};
+
+void pg_set_error(const char* fmt, ...);
+
+#define PG_CHECK(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            pg_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,               \
+                         hipGetErrorString(_e));                                    \
+            return -100;                                                            \
+        }                                                                           \
+    } while (0)
+
+// MFMA wrapper: one 16x16x4 step, D = A(16x4) B(4x16) + C.
+// lane l supplies A[l&15][l>>4] and B[l>>4][l&15] for both dtypes
+// (cdna_hip_programming.md section 3; f64 C/D map differs from f32).
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+    typedef pg_d4 acc_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // row of accumulator register r inside the 16x16 tile
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mfma<float> {
+    typedef pg_f4 acc_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

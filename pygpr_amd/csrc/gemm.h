@@ -1,0 +1,36 @@
+// MFMA GEMM core of libpygpr_hip: one tiled kernel family that carries every O(n^3) step
+// (SYRK / GEMM updates of the Cholesky, TRSM-by-inverse, triangular inverse, L^-T L^-1,
+// predictive-variance product).  fp64 uses v_mfma_f64_16x16x4_f64, fp32 v_mfma_f32_16x16x4_f32.
+#pragma once
+#include "common.h"
+
+// C[M x N] = beta * C + alpha * opA(A) * opB(B)
+//   TA == false: A holds opA as M x K row-major (K contiguous);  TA == true: A holds K x M (M contiguous)
+//   TB == false: B holds opB as K x N row-major (N contiguous);  TB == true: B holds N x K (K contiguous)
+template <typename T> struct GemmP {
+    const T* A;
+    const T* B;
+    T* C;
+    long lda, ldb, ldc;
+    int M, N, K;      // multiples of the block tile / 16
+    T alpha, beta;
+    int tri;          // 1: only tiles on or below the diagonal (BM == BN)
+    int klo, khi;     // K-range from a triangular operand: 0 none, 1 follows the tile row, 2 the tile column
+    long sA, sB, sC;  // batch strides (elements), grid.y = batch
+    int batch;
+    T* part;          // EPI == 1: partial column sums of squares, [M/64][ldp]
+    long ldp;
+    const int* info;  // device flag: kernels exit at once when *info != 0 (failed factorisation)
+};
+
+enum GemmVariant {
+    GEMM_NT_128 = 0,   // C = a A B^T + b C           (SYRK / panel updates)
+    GEMM_NT_RP = 1,    // 64 x 256 row-panel tile: in-place  B <- B inv(L)^T
+    GEMM_NN_128 = 2,   // triangular inverse steps
+    GEMM_TN_128 = 3,   // L^-T L^-1
+    GEMM_NN_128_SS = 4, // C not stored: column sums of squares of the product (predictive variance)
+    GEMM_TT_128 = 5     // C = a A^T B^T (parks (L21 X11)^T in the mirrored block of the triangular inverse)
+};
+
+template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p);
+double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch);

@@ -1,0 +1,264 @@
+// MFMA GEMM core (see gemm.h).  gfx950 only.
+//
+// Block tile BM x BN (128x128, or 64x256 for the in-place row-panel solve), BK = 16, 256 threads =
+// 4 waves, each wave owns a 64x64 sub-tile = 4x4 MFMA tiles of 16x16 (16 accumulators: 128 VGPRs in
+// fp64).  Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile);
+// LDS rows are padded so that the fragment read `lane -> (row l&15, k l>>4)` is bank-conflict free:
+//   K-contiguous operand : LDS [R][BK+2]   (row stride 18 elements == 2 mod 32)
+//   M/N-contiguous one   : LDS [BK][R+16]  (row stride == 16 mod 32)
+// One 16x16x4 fp64 MFMA is 2048 flop in 64 cycles per SIMD (78.6 TFLOP/s chip peak), so a K tile is
+// 4096 MFMA cycles per wave against 8 ds_read_b64 per k-step: the loop is MFMA-bound by construction.
+#include "gemm.h"
+
+#define BK 16
+
+template <typename T, int R, bool KCONT> struct Stage {
+    static constexpr int VE = 16 / sizeof(T);
+    static constexpr int NV = (R * BK / VE) / 256;
+    static constexpr int LDS_ELEMS = KCONT ? R * (BK + 2) : BK * (R + 16);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    typedef T half_t __attribute__((ext_vector_type(VE / 2)));
+    vec_t v[NV];
+
+    __device__ __forceinline__ void load(const T* __restrict__ g, long ld, int r0, int k0, int tid) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = tid + 256 * q;
+            const T* p;
+            if (KCONT) {
+                const int row = idx / (BK / VE), kv = idx % (BK / VE);
+                p = g + (long)(r0 + row) * ld + k0 + kv * VE;
+            } else {
+                const int kr = idx / (R / VE), rv = idx % (R / VE);
+                p = g + (long)(k0 + kr) * ld + r0 + rv * VE;
+            }
+            v[q] = *reinterpret_cast<const vec_t*>(p);
+        }
+    }
+    __device__ __forceinline__ void store(T* s, int tid) const {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int idx = tid + 256 * q;
+            if (KCONT) {
+                const int row = idx / (BK / VE), kv = idx % (BK / VE);
+                T* d = s + row * (BK + 2) + kv * VE;   // 8-byte aligned for fp32, 16 for fp64
+                half_t lo, hi;
+#pragma unroll
+                for (int e = 0; e < VE / 2; ++e) { lo[e] = v[q][e]; hi[e] = v[q][e + VE / 2]; }
+                if (sizeof(T) == 8) {
+                    *reinterpret_cast<vec_t*>(d) = v[q];
+                } else {
+                    *reinterpret_cast<half_t*>(d) = lo;
+                    *reinterpret_cast<half_t*>(d + VE / 2) = hi;
+                }
+            } else {
+                const int kr = idx / (R / VE), rv = idx % (R / VE);
+                *reinterpret_cast<vec_t*>(s + kr * (R + 16) + rv * VE) = v[q];
+            }
+        }
+    }
+    // fragment element for MFMA lane l: (row r0 + (l&15), k kk*4 + (l>>4))
+    static __device__ __forceinline__ T frag(const T* s, int r, int k) {
+        return KCONT ? s[r * (BK + 2) + k] : s[k * (R + 16) + r];
+    }
+};
+
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
+    typedef Stage<T, BM, !TA> SA;   // A: K-contiguous when not transposed
+    typedef Stage<T, BN, TB> SB;    // B: K-contiguous when transposed
+    typedef typename Mfma<T>::acc_t acc_t;
+    constexpr int WN_ = BN / 64;    // waves along N
+
+    if (p.info && *p.info != 0) return;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);
+    T* Bs = As + 2 * SA::LDS_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN_, wn = wave % WN_;
+
+    // XCD-aware tile order: blocks b, b+8, .. share one XCD's L2; give each XCD a contiguous run of
+    // tiles (bijective for any grid size) so neighbouring tiles re-use operand panels from L2.
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+
+    int ti, tj;
+    if (p.tri) {
+        ti = (int)((sqrtf(8.0f * (float)wg + 1.0f) - 1.0f) * 0.5f);
+        while ((long)ti * (ti + 1) / 2 > wg) --ti;
+        while ((long)(ti + 1) * (ti + 2) / 2 <= wg) ++ti;
+        tj = wg - ti * (ti + 1) / 2;
+    } else {
+        const int tn = p.N / BN;
+        ti = wg / tn;
+        tj = wg % tn;
+    }
+    const long zb = blockIdx.y;
+    const T* __restrict__ A = p.A + zb * p.sA;
+    const T* __restrict__ B = p.B + zb * p.sB;
+    T* __restrict__ C = p.C ? p.C + zb * p.sC : nullptr;
+
+    const int m0 = ti * BM, n0 = tj * BN;
+    int kbeg = 0, kend = p.K;
+    int kbw = 0, kew = p.K;   // this wave's own useful K range (16-granular skip inside diagonal tiles)
+    if (p.klo == 1) { kbeg = m0; kbw = m0 + wm * 64; }
+    if (p.klo == 2) { kbeg = n0; kbw = n0 + wn * 64; }
+    if (p.khi == 1) { kend = min(p.K, m0 + BM); kew = min(p.K, m0 + (wm + 1) * 64); }
+    if (p.khi == 2) { kend = min(p.K, n0 + BN); kew = min(p.K, n0 + (wn + 1) * 64); }
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+
+    SA sa;
+    SB sb;
+    const int nk = (kend - kbeg) / BK;
+    if (nk > 0) {
+        sa.load(A, p.lda, m0, kbeg, tid);
+        sb.load(B, p.ldb, n0, kbeg, tid);
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int k0 = kbeg + kt * BK;
+        if (kt + 1 < nk) {
+            sa.load(A, p.lda, m0, k0 + BK, tid);
+            sb.load(B, p.ldb, n0, k0 + BK, tid);
+        }
+        if (k0 + BK > kbw && k0 < kew) {   // wave-uniform
+            const T* as = As + cur * SA::LDS_ELEMS;
+            const T* bs = Bs + cur * SB::LDS_ELEMS;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                T a[4], bq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = SA::frag(as, wm * 64 + i * 16 + fr, kk * 4 + fk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[j] = SB::frag(bs, wn * 64 + j * 16 + fr, kk * 4 + fk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
+            }
+        }
+        if (kt + 1 < nk) {
+            sa.store(As + (cur ^ 1) * SA::LDS_ELEMS, tid);
+            sb.store(Bs + (cur ^ 1) * SB::LDS_ELEMS, tid);
+        }
+        __syncthreads();
+    }
+
+    if (EPI == 0) {
+        const T alpha = p.alpha, beta = p.beta;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * 64 + i * 16 + Mfma<T>::row(lane, r);
+                    const int col = n0 + wn * 64 + j * 16 + fr;
+                    T* c = C + (long)row * p.ldc + col;
+                    T v = alpha * acc[i][j][r];
+                    if (beta != (T)0) v += beta * *c;
+                    *c = v;
+                }
+    } else {
+        // column sums of squares of this wave's 64 rows -> part[(m0/64 + wm)][col]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T s = (T)0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) {
+                const int col = n0 + wn * 64 + j * 16 + lane;
+                p.part[(long)(m0 / 64 + wm) * p.ldp + col + zb * p.sC] = s;
+            }
+        }
+    }
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI>
+static int launch(hipStream_t st, const GemmP<T>& p) {
+    typedef Stage<T, BM, !TA> SA;
+    typedef Stage<T, BN, TB> SB;
+    const size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T);
+    static bool attr_done = false;
+    auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI>;
+    if (!attr_done) {
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (p.M % BM || p.N % BN || p.K % BK || (p.tri && BM != BN)) {
+        pg_set_error("pg_gemm: shape %d x %d x %d not tile aligned (%d x %d)", p.M, p.N, p.K, BM, BN);
+        return -2;
+    }
+    const int tm = p.M / BM, tn = p.N / BN;
+    const long tiles = p.tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
+    if (tiles == 0 || p.batch == 0) return 0;
+    dim3 grid((unsigned)tiles, (unsigned)p.batch, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+
+double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
+    const int BM = (variant == GEMM_NT_RP) ? 64 : 128, BN = (variant == GEMM_NT_RP) ? 256 : 128;
+    const int tm = M / BM, tn = N / BN;
+    double f = 0;
+    for (int ti = 0; ti < tm; ++ti)
+        for (int tj = 0; tj < (tri ? ti + 1 : tn); ++tj) {
+            int kb = 0, ke = K;
+            if (klo == 1) kb = ti * BM;
+            if (klo == 2) kb = tj * BN;
+            if (khi == 1) ke = std::min(K, (ti + 1) * BM);
+            if (khi == 2) ke = std::min(K, (tj + 1) * BN);
+            if (ke > kb) f += 2.0 * BM * BN * (double)(ke - kb);
+        }
+    return f * batch;
+}
+
+template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p) {
+    const bool prof = ctx && ctx->prof_on;
+    if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
+    int rc;
+    switch (variant) {
+        case GEMM_NT_128: rc = launch<T, false, true, 128, 128, 0>(st, p); break;
+        case GEMM_NT_RP: rc = launch<T, false, true, 64, 256, 0>(st, p); break;
+        case GEMM_NN_128: rc = launch<T, false, false, 128, 128, 0>(st, p); break;
+        case GEMM_TN_128: rc = launch<T, true, false, 128, 128, 0>(st, p); break;
+        case GEMM_NN_128_SS: rc = launch<T, false, false, 128, 128, 1>(st, p); break;
+        case GEMM_TT_128: rc = launch<T, true, true, 128, 128, 0>(st, p); break;
+        default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
+    }
+    if (rc) return rc;
+    if (prof) {
+        PG_CHECK(hipEventRecord(ctx->ev[7], st));
+        PG_CHECK(hipEventSynchronize(ctx->ev[7]));
+        float ms = 0;
+        PG_CHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
+        ctx->prof_ms += ms;
+        ctx->prof_flops += pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch);
+        ctx->prof_launches += 1;
+    }
+    return 0;
+}
+
+template int pg_gemm<double>(pg_ctx*, hipStream_t, int, const GemmP<double>&);
+template int pg_gemm<float>(pg_ctx*, hipStream_t, int, const GemmP<float>&);

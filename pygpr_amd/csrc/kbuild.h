@@ -1,0 +1,12 @@
+#pragma once
+#include "common.h"
+#include "pygpr_hip.h"
+
+template <typename T>
+int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
+              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, double jitter, T* K,
+              long ldk, int rows_pad, int cols_pad);
+template <typename T>
+int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,
+                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork);
+long pg_nlml_grad_worksize_impl(int n, int nhp);

@@ -1,0 +1,315 @@
+// Covariance assembly (HBM-bound, O(n^2 d)) and the fused NLML-gradient contraction.
+//
+// pg_kbuild: K[i][j] = sum_c k_c(r_i, c_j) (+ (sum sigma_n^2 + jitter) on the diagonal of a symmetric
+// build); k_c is the ARD squared exponential of PyGPR/covar.py:129-167 (hp = [sigma, l_1..l_d], l are
+// INVERSE length scales, no 1/2 in the exponent) or Matern-5/2 with the same hp layout.  Distances are
+// direct sums of squared differences (exactly symmetric, never negative) instead of the reference's
+// GEMM expansion (covar.py:102-127).  One 64x64 output tile per 256-thread workgroup; both point tiles
+// are staged in LDS k-major ([d][64]); each thread owns a 4x4 micro-tile whose columns are two 16-byte
+// vectors, so every store instruction writes 256 contiguous bytes per row.  Rows/columns >= the real
+// point count are padding: identity for a symmetric build (keeps the padded Cholesky trivial), zero
+// for a cross build.
+//
+// pg_nlml_grad: g_k = 1/2 sum_ij (K^-1 - a a^T)_ij dK_ij/dtheta_k over the lower triangle, with dK
+// recomputed from the point tiles on the fly: dK/dsigma = 2K/sigma, dK/dl_k = -2 l_k D_k^2 K
+// (covar.py:169-206), dK/dsigma_n = 2 sigma_n I (covar.py:247-269).  The reference materialises
+// dK[nhp,n,n] and solves against it (loss.py:116-121); this is the same number by the K^-1 route.
+#include "kbuild.h"
+
+#define KT 64
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+
+template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, T sqd) {
+    if (kind == PG_KIND_RBF) return sig2 * exp(-sqd);
+    const T s5 = (T)2.23606797749978969641;
+    const T r = sqrt(sqd);
+    return sig2 * ((T)1 + s5 * r + (T)(5.0 / 3.0) * sqd) * exp(-s5 * r);
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_points(T* dst, const T* __restrict__ X, long ldx, int npts, int p0, int d, int tid) {
+    // dst[k][64] <- X[p0 + p][k]; points beyond npts read as zero
+    for (int idx = tid; idx < KT * d; idx += 256) {
+        const int p = idx / d, k = idx % d;
+        const int gp = p0 + p;
+        dst[k * KT + p] = (gp < npts) ? X[(long)gp * ldx + k] : (T)0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
+                                                        const T* __restrict__ Xr, long ldr, int nr,
+                                                        const T* __restrict__ Xc, long ldc, int nc, int d,
+                                                        int symmetric, int lower_only, double jitter,
+                                                        T* __restrict__ K, long ldk) {
+    const int tc = blockIdx.x, tr = blockIdx.y;
+    if (lower_only && tc > tr) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* xr = reinterpret_cast<T*>(smem_raw);
+    T* xc = xr + KT * d;
+    T* l2 = xc + KT * d;   // [ncomp][d] squared inverse length scales
+    const int tid = threadIdx.x;
+    stage_points(xr, Xr, ldr, nr, tr * KT, d, tid);
+    stage_points(xc, Xc, ldc, nc, tc * KT, d, tid);
+    for (int idx = tid; idx < spec.ncomp * d; idx += 256) {
+        const int c = idx / d, k = idx % d;
+        const double l = hp[spec.off[c] + 1 + k];
+        l2[idx] = (T)(l * l);
+    }
+    __syncthreads();
+
+    constexpr int VE = VecOf<T>::N, NVC = 4 / VE;   // vectors per row of the micro-tile
+    const int tx = tid & 15, ty = tid >> 4;
+    T out[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[r][c] = (T)0;
+
+    for (int cp = 0; cp < spec.ncomp; ++cp) {
+        const double sg = hp[spec.off[cp]];
+        const T sig2 = (T)(sg * sg);
+        const T* lc = l2 + cp * d;
+        T sq[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sq[r][c] = (T)0;
+        for (int k = 0; k < d; ++k) {
+            const T w = lc[k];
+            T a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = xr[k * KT + ty * 4 + r];
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) b[v * VE + e] = xc[k * KT + v * (16 * VE) + tx * VE + e];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const T df = a[r] - b[c];
+                    sq[r][c] += w * df * df;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[r][c] += comp_value<T>(spec.kind[cp], sig2, sq[r][c]);
+    }
+    double dg = jitter;
+    for (int i = 0; i < spec.nnoise; ++i) { const double s = hp[spec.noise_off[i]]; dg += s * s; }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = tr * KT + ty * 4 + r;
+#pragma unroll
+        for (int v = 0; v < NVC; ++v) {
+            typename VecOf<T>::type vec;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const int gj = tc * KT + v * (16 * VE) + tx * VE + e;
+                T val = out[r][v * VE + e];
+                if (gi >= nr || gj >= nc) val = (symmetric && gi == gj) ? (T)1 : (T)0;
+                else if (symmetric && gi == gj) val += (T)dg;
+                vec[e] = val;
+            }
+            *reinterpret_cast<typename VecOf<T>::type*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE) = vec;
+        }
+    }
+}
+
+template <typename T>
+int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
+              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, double jitter, T* K,
+              long ldk, int rows_pad, int cols_pad) {
+    if (rows_pad % KT || cols_pad % KT || d < 1 || d > PG_MAX_DIM) {
+        pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
+        return -2;
+    }
+    const size_t lds = (size_t)(2 * KT * d + spec.ncomp * d) * sizeof(T);
+    dim3 grid(cols_pad / KT, rows_pad / KT);
+    hipLaunchKernelGGL(pg_kbuild_kernel<T>, grid, dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
+                       symmetric, lower_only, jitter, K, ldk);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+template int pg_kbuild<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int,
+                               const double*, long, int, int, int, int, double, double*, long, int, int);
+template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int,
+                              const float*, long, int, int, int, int, double, float*, long, int, int);
+
+// ------------------------------------------------------------------------------------------------
+// fused gradient contraction
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void pg_grad_kernel(pg_covspec spec, const double* __restrict__ hp,
+                                                      const T* __restrict__ X, long ldx, int n, int d,
+                                                      const T* __restrict__ Kinv, long ldk,
+                                                      const T* __restrict__ alpha, double* __restrict__ part,
+                                                      int nhp) {
+    const int tc = blockIdx.x, tr = blockIdx.y;
+    const int blk = tr * gridDim.x + tc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tc > tr) {   // upper tiles contribute nothing; their partial row must still be zero
+        for (int idx = tid; idx < nhp; idx += 256) part[(long)blk * nhp + idx] = 0.0;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* red = reinterpret_cast<double*>(smem_raw);             // [4 waves][DMAX + 2]
+    T* xr = reinterpret_cast<T*>(red + 4 * (DMAX + 2));             // [DMAX][64], zero for k >= d
+    T* xc = xr + KT * DMAX;
+    T* l2 = xc + KT * DMAX;                                         // [ncomp][DMAX], zero for k >= d
+    for (int idx = tid; idx < KT * DMAX; idx += 256) {
+        const int p = idx / DMAX, k = idx % DMAX;
+        const int gr = tr * KT + p, gc = tc * KT + p;
+        xr[k * KT + p] = (k < d && gr < n) ? X[(long)gr * ldx + k] : (T)0;
+        xc[k * KT + p] = (k < d && gc < n) ? X[(long)gc * ldx + k] : (T)0;
+    }
+    for (int idx = tid; idx < spec.ncomp * DMAX; idx += 256) {
+        const int c = idx / DMAX, k = idx % DMAX;
+        const double l = (k < d) ? hp[spec.off[c] + 1 + k] : 0.0;
+        l2[idx] = (T)(l * l);
+    }
+    __syncthreads();
+
+    // element e of this thread: row = 4 e + wave (one wave reads one 64-wide row: 512 contiguous bytes),
+    // column = lane.  W = weight * (Kinv - a a^T): 2 below the diagonal, 1 on it, 0 above / in padding.
+    const int gj = tc * KT + lane;
+    const double aj = (gj < n) ? (double)alpha[gj] : 0.0;
+    double tr_w = 0.0;
+    for (int cp = 0; cp < spec.ncomp; ++cp) {
+        const int o = spec.off[cp];
+        const double sg = hp[o];
+        const T sig2 = (T)(sg * sg);
+        const T* lc = l2 + cp * DMAX;
+        const int kind = spec.kind[cp];
+        double acc[DMAX + 1];
+#pragma unroll
+        for (int k = 0; k <= DMAX; ++k) acc[k] = 0.0;
+#pragma unroll 2
+        for (int e = 0; e < 16; ++e) {
+            const int row = 4 * e + wave;
+            const int gi = tr * KT + row;
+            double w = 0.0;
+            if (gi < n && gj <= gi) {
+                w = (double)Kinv[(long)gi * ldk + gj] - (double)alpha[gi] * aj;
+                if (gj < gi) w *= 2.0; else if (cp == 0) tr_w += w;
+            }
+            T sq = (T)0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const T df = xr[k * KT + row] - xc[k * KT + lane];
+                sq += lc[k] * df * df;
+            }
+            double kv, base;   // dK/dl_k = base * l_k * D_k^2 (sign and constants applied in the reduce)
+            if (kind == PG_KIND_RBF) {
+                kv = (double)(sig2 * exp(-sq));
+                base = kv;
+            } else {
+                const T s5 = (T)2.23606797749978969641;
+                const T rr = sqrt(sq), ex = exp(-s5 * rr);
+                kv = (double)(sig2 * ((T)1 + s5 * rr + (T)(5.0 / 3.0) * sq) * ex);
+                base = (double)(sig2 * ((T)1 + s5 * rr) * ex);
+            }
+            acc[0] += w * kv;
+            const double wb = w * base;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const double df = (double)(xr[k * KT + row] - xc[k * KT + lane]);
+                acc[1 + k] += wb * df * df;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k <= DMAX; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) red[wave * (DMAX + 2) + k] = s;
+        }
+        __syncthreads();
+        if (tid <= d)
+            part[(long)blk * nhp + o + tid] =
+                red[tid] + red[(DMAX + 2) + tid] + red[2 * (DMAX + 2) + tid] + red[3 * (DMAX + 2) + tid];
+        __syncthreads();
+    }
+    if (spec.ncomp == 0) {   // pure white noise: the trace still needs the diagonal of W
+        for (int e = 0; e < 16; ++e) {
+            const int gi = tr * KT + 4 * e + wave;
+            if (gi < n && gj == gi) tr_w += (double)Kinv[(long)gi * ldk + gj] - (double)alpha[gi] * aj;
+        }
+    }
+    {
+        const double s = wave_sum(tr_w);
+        if (lane == 0) red[wave * (DMAX + 2)] = s;
+        __syncthreads();
+        if (tid < spec.nnoise)
+            part[(long)blk * nhp + spec.noise_off[tid]] =
+                red[0] + red[DMAX + 2] + red[2 * (DMAX + 2)] + red[3 * (DMAX + 2)];
+    }
+}
+
+// grad[p] = scale_p * sum_blocks part[b][p]
+__global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, const double* __restrict__ hp,
+                                                             const double* __restrict__ part, int nblk, int nhp,
+                                                             int d, double* __restrict__ grad) {
+    __shared__ double red[4];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int b = tid; b < nblk; b += 256) s += part[(long)b * nhp + p];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        s = red[0] + red[1] + red[2] + red[3];
+        double scale = 0.0;
+        for (int c = 0; c < spec.ncomp; ++c) {
+            const int o = spec.off[c];
+            if (p == o) scale = 0.5 * 2.0 / hp[o];                        // dK/dsigma = 2K/sigma
+            else if (p > o && p <= o + d)
+                scale = (spec.kind[c] == PG_KIND_RBF) ? 0.5 * -2.0 * hp[p]   // -2 l_k D_k^2 K
+                                                      : 0.5 * -(5.0 / 3.0) * hp[p];
+        }
+        for (int i = 0; i < spec.nnoise; ++i)
+            if (p == spec.noise_off[i]) scale = 0.5 * 2.0 * hp[p];        // dK/dsigma_n = 2 sigma_n I
+        grad[p] = scale * s;
+    }
+}
+
+template <typename T, int DMAX>
+static int launch_grad(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n,
+                       int d, const T* Kinv, long ldk, const T* alpha, double* part, int nhp, int tiles) {
+    const size_t lds = (size_t)(2 * KT * DMAX + PG_MAX_COMP * DMAX) * sizeof(T) + 4 * (DMAX + 2) * sizeof(double);
+    hipLaunchKernelGGL((pg_grad_kernel<T, DMAX>), dim3(tiles, tiles), dim3(256), lds, st, spec, hp, X, ldx, n, d,
+                       Kinv, ldk, alpha, part, nhp);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,
+                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork) {
+    const int tiles = (n + KT - 1) / KT;
+    const long need = (long)tiles * tiles * nhp;
+    if (lwork < need) { pg_set_error("pg_nlml_grad: workspace %ld < %ld doubles", lwork, need); return -3; }
+    int rc;
+    if (d <= 4) rc = launch_grad<T, 4>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else if (d <= 8) rc = launch_grad<T, 8>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else if (d <= 16) rc = launch_grad<T, 16>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else if (d <= 32) rc = launch_grad<T, 32>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else if (d <= 64) rc = launch_grad<T, 64>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else { pg_set_error("pg_nlml_grad: d=%d > %d", d, PG_MAX_DIM); return -2; }
+    if (rc) return rc;
+    hipLaunchKernelGGL(pg_grad_reduce_kernel, dim3(nhp), dim3(256), 0, st, spec, hp, work, tiles * tiles, nhp, d, grad);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+long pg_nlml_grad_worksize_impl(int n, int nhp) {
+    const long tiles = (n + KT - 1) / KT;
+    return tiles * tiles * nhp;
+}
+template int pg_nlml_grad_t<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int, int,
+                                    const double*, long, const double*, double*, int, double*, long);
+template int pg_nlml_grad_t<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int, int,
+                                   const float*, long, const float*, double*, int, double*, long);

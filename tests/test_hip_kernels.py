@@ -1,0 +1,331 @@
+"""GPU parity tests of the individual C-ABI entry points (through ctypes) against NumPy / the CPU oracle.
+fp64 tolerances are stated per test; fp32 runs are compared with the fp64 answer at 1e-3 class."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pygpr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pygpr_amd._ops import get_ops
+
+    return get_ops()
+
+
+def dev(a, dtype=torch.float64):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+def spd(n, rng, cond_shift=1.0):
+    a = rng.standard_normal((n, n))
+    return a @ a.T / n + cond_shift * np.eye(n)
+
+
+# --------------------------------------------------------------------------- GEMM core
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("variant", ["NT", "NN", "TN", "TT"])
+def test_gemm_variants(ops, variant, dtype, tol):
+    from pygpr_amd._lib import GEMM_NN, GEMM_NT, GEMM_TN, GEMM_TT
+
+    rng = np.random.default_rng(0)
+    m, n, k = 256, 384, 208
+    opa, opb = rng.standard_normal((m, k)), rng.standard_normal((k, n))
+    c0 = rng.standard_normal((m, n))
+    code = {"NT": GEMM_NT, "NN": GEMM_NN, "TN": GEMM_TN, "TT": GEMM_TT}[variant]
+    a = dev(opa.T if variant[0] == "T" else opa, dtype)
+    b = dev(opb.T if variant[1] == "T" else opb, dtype)
+    c = dev(c0, dtype)
+    ops.gemm_raw(code, m, n, k, -0.5, a, b, 2.0, c)
+    ref = -0.5 * opa @ opb + 2.0 * c0
+    np.testing.assert_allclose(host(c), ref, atol=tol * k, rtol=0)
+    # asymmetric-B identity check (guards a swapped C/D register map)
+    eye = dev(np.eye(256), dtype)
+    basym = rng.standard_normal((256, 256))
+    c = dev(np.zeros((256, 256)), dtype)
+    ops.gemm_raw(GEMM_NN, 256, 256, 256, 1.0, eye, dev(basym, dtype), 0.0, c)
+    np.testing.assert_allclose(host(c), basym, atol=1e-6 if dtype == torch.float32 else 0)
+
+
+def test_gemm_row_panel_inplace_and_tri(ops):
+    from pygpr_amd._lib import GEMM_NT, GEMM_NT_RP
+
+    rng = np.random.default_rng(1)
+    # in-place B <- B inv^T with a lower-triangular inv (khi = 2 skips k > column)
+    m = 320
+    bmat = rng.standard_normal((m, 256))
+    inv = np.tril(rng.standard_normal((256, 256)))
+    b = dev(bmat)
+    ops.gemm_raw(GEMM_NT_RP, m - m % 64, 256, 256, 1.0, b, dev(inv), 0.0, b, khi=2)
+    np.testing.assert_allclose(host(b), bmat @ inv.T, atol=1e-11)
+    # SYRK on lower tiles only: tiles above the diagonal stay untouched
+    n, k = 512, 256
+    p = rng.standard_normal((n, k))
+    c0 = rng.standard_normal((n, n))
+    c = dev(c0)
+    pd = dev(p)
+    ops.gemm_raw(GEMM_NT, n, n, k, -1.0, pd, pd, 1.0, c, tri=1)
+    got, ref = host(c), c0 - p @ p.T
+    for ti in range(n // 128):
+        for tj in range(n // 128):
+            blk = (slice(ti * 128, ti * 128 + 128), slice(tj * 128, tj * 128 + 128))
+            np.testing.assert_allclose(got[blk], ref[blk] if tj <= ti else c0[blk], atol=1e-11)
+
+
+def test_gemm_triangular_k_ranges(ops):
+    from pygpr_amd._lib import GEMM_NN, GEMM_TN
+
+    rng = np.random.default_rng(2)
+    n = 512
+    low = np.tril(rng.standard_normal((n, n)))
+    dense = rng.standard_normal((n, n))
+    # khi = 1: lower-triangular left operand
+    c = dev(np.zeros((n, n)))
+    ops.gemm_raw(GEMM_NN, n, n, n, 1.0, dev(low), dev(dense), 0.0, c, khi=1)
+    np.testing.assert_allclose(host(c), low @ dense, atol=1e-11)
+    # klo = 2: lower-triangular right operand
+    c = dev(np.zeros((n, n)))
+    ops.gemm_raw(GEMM_NN, n, n, n, 1.0, dev(dense), dev(low), 0.0, c, klo=2)
+    np.testing.assert_allclose(host(c), dense @ low, atol=1e-11)
+    # klo = 1 on lower tiles: low^T low
+    c = dev(np.zeros((n, n)))
+    ld = dev(low)
+    ops.gemm_raw(GEMM_TN, n, n, n, 1.0, ld, ld, 0.0, c, tri=1, klo=1)
+    np.testing.assert_allclose(np.tril(host(c)), np.tril(low.T @ low), atol=1e-11)
+
+
+# --------------------------------------------------------------------------- covariance build
+def _spec(covs, d):
+    from pygpr_amd._lib import PG_KIND_MATERN52, PG_KIND_RBF
+    from pygpr_amd._ops import make_spec
+
+    kinds, offs, noise, o = [], [], [], 0
+    for c in covs:
+        if c.kind == "wn":
+            noise.append(o)
+            o += 1
+        else:
+            kinds.append(PG_KIND_RBF if c.kind == "se" else PG_KIND_MATERN52)
+            offs.append(o)
+            o += d + 1
+    return make_spec(kinds, offs, noise)
+
+
+@pytest.mark.parametrize("covs", [[orc.SE, orc.WN], [orc.SE, orc.SE, orc.WN], [orc.M52, orc.WN], [orc.WN, orc.SE]])
+@pytest.mark.parametrize("n,d", [(10, 2), (200, 5), (300, 16)])
+def test_kernel_build(ops, covs, n, d):
+    from pygpr_amd._ops import pad_to
+
+    rng = np.random.default_rng(n + d)
+    x, xp = rng.random((n, d)), rng.random((37, d))
+    hp = np.concatenate([0.5 + rng.random(c.nhp(d)) if c.kind != "wn" else 0.05 + 0.1 * rng.random(1) for c in covs])
+    spec, npad, mpad = _spec(covs, d), pad_to(n), pad_to(37)
+    hpd, xd, xpd = dev(hp), dev(x), dev(xp)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(spec, hpd, xd, None, k, jitter=1e-7)
+    ref = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    got = host(k)
+    np.testing.assert_allclose(got[:n, :n], ref, atol=1e-14, rtol=1e-14)
+    assert np.array_equal(got[:n, :n], got[:n, :n].T)            # exactly symmetric
+    pad_ref = np.eye(npad)
+    pad_ref[:n, :n] = got[:n, :n]
+    assert np.array_equal(got, pad_ref)                           # identity padding
+    # cross build, train rows x test columns (transposed w.r.t. the reference's [m, n])
+    ks = ops.empty(npad, mpad)
+    ops.kernel_build(spec, hpd, xd, xpd, ks)
+    ref_ks = orc.kernel(covs, hp, x, xp, form="direct").T
+    got = host(ks)
+    np.testing.assert_allclose(got[:n, :37], ref_ks, atol=1e-14, rtol=1e-14)
+    assert not got[n:, :].any() and not got[:, 37:].any()
+    # lower-only build leaves tiles above the diagonal untouched
+    kl = ops.zeros(npad, npad) - 7.0
+    ops.kernel_build(spec, hpd, xd, None, kl, lower_only=True, jitter=1e-7)
+    gl = host(kl)
+    np.testing.assert_array_equal(np.tril(gl), np.tril(host(k)))
+    if npad >= 128:
+        assert (gl[:64, 64:128] == -7.0).all()
+
+
+def test_kernel_build_fp32(ops):
+    from pygpr_amd._ops import pad_to
+
+    rng = np.random.default_rng(9)
+    n, d = 300, 8
+    x = rng.random((n, d))
+    covs = [orc.M52, orc.WN]
+    hp = np.concatenate([[1.2], 0.5 + rng.random(d), [0.1]])
+    k = ops.empty(pad_to(n), pad_to(n), dtype=torch.float32)
+    ops.kernel_build(_spec(covs, d), dev(hp), dev(x, torch.float32), None, k, jitter=1e-7)
+    np.testing.assert_allclose(host(k)[:n, :n], orc.kernel(covs, hp, x) + 1e-7 * np.eye(n), atol=5e-6)
+
+
+# --------------------------------------------------------------------------- Cholesky & friends
+@pytest.mark.parametrize("n", [256, 768, 1280])
+def test_potrf_solves_inverse(ops, n):
+    rng = np.random.default_rng(n)
+    a = spd(n, rng)
+    ad = dev(a)
+    invd = ops.potrf_workspace(n, torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(ad, invd, info)
+    assert int(info.item()) == 0
+    chol = np.linalg.cholesky(a)
+    np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-12)
+    # alpha = A^-1 y
+    y = rng.standard_normal(n)
+    xd = ops.empty(n)
+    ops.potrs_vec(ad, invd, dev(y), xd)
+    np.testing.assert_allclose(host(xd), np.linalg.solve(a, y), rtol=1e-9, atol=1e-10)
+    # Minv = L^-1
+    minv = ops.zeros(n, n)
+    ops.trtri(ad, invd, minv)
+    linv = np.linalg.inv(chol)
+    got = host(minv)
+    for ti in range(n // 128):   # strictly upper 128-tiles outside the diagonal 256-blocks are scratch
+        for tj in range(ti + 1):
+            blk = (slice(ti * 128, ti * 128 + 128), slice(tj * 128, tj * 128 + 128))
+            np.testing.assert_allclose(got[blk], linv[blk], atol=1e-11)
+    # trmv both ways
+    v = rng.standard_normal(n)
+    out = ops.empty(n)
+    work = ops.empty((n // 256) * n)
+    ops.trmv(minv, dev(v), out, 0)
+    np.testing.assert_allclose(host(out), linv @ v, atol=1e-11)
+    ops.trmv(minv, dev(v), out, 1, work)
+    np.testing.assert_allclose(host(out), linv.T @ v, atol=1e-11)
+    # Kinv = Minv^T Minv
+    kinv = ops.zeros(n, n)
+    ops.lauum(minv, kinv)
+    np.testing.assert_allclose(np.tril(host(kinv)), np.tril(np.linalg.inv(a)), atol=1e-10)
+    # tril export
+    ops.tril(ad, n)
+    np.testing.assert_allclose(host(ad), chol, atol=1e-12)
+
+
+def test_potrf_not_positive_definite_reports_minor(ops):
+    rng = np.random.default_rng(4)
+    n = 512
+    a = spd(n, rng)
+    a[300, 300] = -1.0   # leading minor of order 301 fails
+    ad = dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
+    assert int(info.item()) == 301
+
+
+def test_potrf_fp32(ops):
+    rng = np.random.default_rng(5)
+    n = 512
+    a = spd(n, rng, 2.0)
+    ad = dev(a, torch.float32)
+    invd = ops.potrf_workspace(n, torch.float32)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(ad, invd, info)
+    assert int(info.item()) == 0
+    np.testing.assert_allclose(np.tril(host(ad)), np.linalg.cholesky(a), atol=2e-5)
+    minv = ops.zeros(n, n, dtype=torch.float32)
+    ops.trtri(ad, invd, minv)
+    kinv = ops.zeros(n, n, dtype=torch.float32)
+    ops.lauum(minv, kinv)
+    np.testing.assert_allclose(np.tril(host(kinv)), np.tril(np.linalg.inv(a)), atol=2e-4)
+
+
+# --------------------------------------------------------------------------- NLML pieces
+@pytest.mark.parametrize("covs,d", [([orc.SE, orc.WN], 3), ([orc.SE, orc.SE, orc.WN], 8), ([orc.M52, orc.WN], 5),
+                                    ([orc.SE, orc.WN], 16)])
+def test_nlml_value_and_grad(ops, covs, d):
+    from pygpr_amd._ops import pad_to
+
+    n = 333
+    x, y = orc.synth(n, d, seed=d)
+    rng = np.random.default_rng(d)
+    hp = np.concatenate([0.6 + 0.6 * rng.random(c.nhp(d)) if c.kind != "wn" else np.array([0.1]) for c in covs])
+    npad = pad_to(n)
+    spec = _spec(covs, d)
+    hpd, xd = dev(hp), dev(x)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(spec, hpd, xd, None, k, lower_only=True, jitter=1e-7)
+    invd = ops.potrf_workspace(npad, torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(k, invd, info)
+    assert int(info.item()) == 0
+    ypad = ops.zeros(npad)
+    ypad[:n] = dev(y)
+    alpha = ops.empty(npad)
+    ops.potrs_vec(k, invd, ypad, alpha)
+    out = ops.zeros(1 + hp.size)
+    ops.nlml_value(k, ypad, alpha, n, out)
+    minv = ops.zeros(npad, npad)
+    ops.trtri(k, invd, minv)
+    kinv = ops.zeros(npad, npad)
+    ops.lauum(minv, kinv)
+    work = ops.empty(ops.nlml_grad_worksize(n, hp.size))
+    ops.nlml_grad(spec, hpd, xd, n, kinv, alpha, out[1:], work)
+    loss_ref, grad_ref = orc.mle_loss_and_grad(covs, hp, x, y, "kinv", form="direct")
+    got = host(out)
+    np.testing.assert_allclose(got[0], loss_ref, rtol=1e-11)
+    np.testing.assert_allclose(got[1:], grad_ref, rtol=1e-8, atol=1e-9 * np.abs(grad_ref).max())
+
+
+def test_predict_mean_q(ops):
+    from pygpr_amd._ops import pad_to
+
+    n, d, m = 500, 4, 70
+    covs = [orc.SE, orc.WN]
+    x, y = orc.synth(n, d, seed=3)
+    xp = np.random.default_rng(8).random((m, d))
+    hp = np.array([1.0, 0.8, 1.1, 0.9, 1.2, 0.1])
+    npad, mpad = pad_to(n), pad_to(m)
+    spec = _spec(covs, d)
+    hpd, xd, xpd = dev(hp), dev(x), dev(xp)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(spec, hpd, xd, None, k, jitter=1e-7)
+    invd = ops.potrf_workspace(npad, torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(k, invd, info)
+    ypad = ops.zeros(npad)
+    ypad[:n] = dev(y)
+    alpha = ops.empty(npad)
+    ops.potrs_vec(k, invd, ypad, alpha)
+    minv = ops.zeros(npad, npad)
+    ops.trtri(k, invd, minv)
+    ks = ops.empty(npad, mpad)
+    ops.kernel_build(spec, hpd, xd, xpd, ks)
+    mean, q = ops.empty(mpad), ops.empty(mpad)
+    work = ops.empty((npad // 64) * mpad)
+    ops.predict_mean_q(ks, minv, alpha, mean, q, work)
+    mu_ref, var_ref = orc.gp_predict(covs, hp, x, y, xp, "diag", form="direct")
+    kss = hp[0] ** 2 + hp[-1] ** 2
+    np.testing.assert_allclose(host(mean)[:m], mu_ref, atol=1e-10)
+    np.testing.assert_allclose(kss - host(q)[:m], var_ref, atol=1e-11)
+    # full covariance pieces: V = Minv Ks, C = Kss - V^T V
+    v = ops.empty(npad, mpad)
+    ops.trmm_lower(minv, ks, v)
+    c = ops.zeros(mpad, mpad)
+    c[:m, :m] = dev(orc.kernel(covs, hp, xp, form="direct"))
+    ops.syrk_tn_sub(v, c)
+    _, cov_ref = orc.gp_predict(covs, hp, x, y, xp, "full", form="direct")
+    np.testing.assert_allclose(np.tril(host(c)[:m, :m]), np.tril(cov_ref), atol=1e-11)
+
+
+def test_grbcm_terms(ops):
+    rng = np.random.default_rng(6)
+    m = 300
+    mc, vc, vg, mg = rng.standard_normal(m), 0.1 + rng.random(m), 0.2 + rng.random(m), rng.standard_normal(m)
+    out = ops.zeros(3, m)
+    ops.grbcm_local_terms(dev(mc), dev(vc), dev(vg), True, False, out)
+    ops.grbcm_local_terms(dev(mc * 0.5), dev(vc * 1.3), dev(vg), False, True, out)
+    ref = orc.grbcm_terms(mc, vc, vg, True) + orc.grbcm_terms(mc * 0.5, vc * 1.3, vg, False)
+    np.testing.assert_allclose(host(out), ref, rtol=1e-13)
+    mean, var = ops.empty(m), ops.empty(m)
+    ops.grbcm_finish(out, dev(mg), dev(vg), mean, var)
+    mu_ref, var_ref = orc.grbcm_finish(ref, mg, vg)
+    np.testing.assert_allclose(host(mean), mu_ref, rtol=1e-12)
+    np.testing.assert_allclose(host(var), var_ref, rtol=1e-12)
