@@ -58,6 +58,11 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
                     int nr, const void* Xc, long ldc, int nc, int d, int lower_only, double jitter, void* K,
                     long ldk, int rows_pad, int cols_pad, void* stream);
 
+/* dK[nhp][n][n] (contiguous, unpadded): the stack Covar.kernel_and_grad returns (covar.py:64-81,
+ * 169-206, 247-269).  Drop-in surface only -- the NLML path never materialises it. */
+int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
+                         int n, int d, void* dK, void* stream);
+
 /* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag receives the
  * inverses of the 256x256 diagonal blocks ([n/256][256][256]); they drive every later solve. */
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
@@ -93,25 +98,30 @@ int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* h
 
 /* Predictive mean and variance from Ks[n_pad x m_pad] = k(X, Xp) (train rows, test columns):
  *   mean[j] = sum_i Ks[i][j] alpha[i]                 (gpr.py:80-85)
- *   q[j]    = sum_i (Minv Ks)[i][j]^2                 (gpr.py:100-104: rowsum(K* o (K^-1 K*^T)^T))
- * the caller forms var = k** - q (gpr.py:98,102).  work: (n_pad/64) * m_pad elements. */
+ *   var[j]  = kss - sum_i (Minv Ks)[i][j]^2           (gpr.py:98-104: diag(K**) - rowsum(K* o (K^-1 K*^T)^T))
+ * kss = the constant diagonal of K** (sum sigma^2 + sum sigma_n^2); var == NULL skips the variance.
+ * work: (n_pad/64) * m_pad elements. */
 int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv,
-                      long ldm, const void* alpha, void* mean, void* q, void* work, void* stream);
+                      long ldm, const void* alpha, void* mean, void* var, double kss, void* work, void* stream);
 
 /* Dense product V = Minv Ks written out (needed for the full predictive covariance, gpr.py:108-120),
- * and C = C - V^T V on m_pad x m_pad (lower tiles). */
+ * and C = C - V^T V on m_pad x m_pad (lower_only != 0: tiles on/below the diagonal only). */
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks,
                   long ldks, void* V, long ldv, void* stream);
 int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc,
-                   void* stream);
+                   int lower_only, void* stream);
 
 /* Per-expert grBCM terms (gr_bcm.py:125-144): out[0..2][j] = beta, beta*prec, beta*prec*mean with
- * beta = 1/2 (log prec_c - log prec_g), or 1 when is_first (gr_bcm.py:132); accumulate != 0 adds. */
+ * beta = 1/2 (log prec_c - log prec_g), or 1 when is_first (gr_bcm.py:132); accumulate != 0 adds.
+ * beta_out / prec_out (nullable, length m) receive this expert's row of GRBCM.beta / GRBCM.prec
+ * (gr_bcm.py:135-136). */
 int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
-                         int is_first, int accumulate, double* out, long ldo, void* stream);
-/* Finish the committee (gr_bcm.py:133,143,144) from the summed terms and the global expert. */
+                         int is_first, int accumulate, double* out, long ldo, double* beta_out, double* prec_out,
+                         void* stream);
+/* Finish the committee (gr_bcm.py:133,143,144) from the summed terms and the global expert; beta0 / prec0
+ * (nullable) receive the global expert's row of GRBCM.beta / GRBCM.prec. */
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g,
-                    const void* var_g, void* mean, void* var, void* stream);
+                    const void* var_g, void* mean, void* var, double* beta0, double* prec0, void* stream);
 
 /* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);

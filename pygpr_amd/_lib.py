@@ -36,6 +36,7 @@ _SIGS = {
     "pg_create": (_i, [C.POINTER(_vp)]),
     "pg_destroy": (_i, [_vp]),
     "pg_kernel_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _vp, _l, _i, _i, _i, _d, _vp, _l, _i, _i, _vp]),
+    "pg_kernel_grad_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _vp]),
     "pg_potrf_worksize": (_l, [_i, _i]),
     "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
@@ -45,11 +46,11 @@ _SIGS = {
     "pg_nlml_value": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
     "pg_nlml_grad_worksize": (_l, [_i, _i]),
     "pg_nlml_grad": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
-    "pg_predict_mean_q": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "pg_predict_mean_q": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _d, _vp, _vp]),
     "pg_trmm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
-    "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
-    "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp]),
-    "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
+    "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
+    "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),

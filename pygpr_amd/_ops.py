@@ -72,6 +72,14 @@ class HipOps:
             _p(out), out.stride(0), out.shape[0], out.shape[1], self._st()), "pg_kernel_build")
         return out
 
+    def kernel_grad_build(self, spec, hp, x, out):
+        """out[nhp, n, n] <- dK/dtheta stack (public Covar.kernel_and_grad only)."""
+        self._chk(hp, x, out)
+        n, d = x.shape
+        _lib.check(self.lib.pg_kernel_grad_build(self.h, _code(out.dtype), C.byref(spec), _p(hp), _p(x), x.stride(0),
+                                                 n, d, _p(out), self._st()), "pg_kernel_grad_build")
+        return out
+
     # -- factorisation and solves -------------------------------------------------------------
     def potrf_workspace(self, n_pad, dtype):
         return self.empty(self.lib.pg_potrf_worksize(_code(dtype), n_pad), dtype=dtype)
@@ -121,34 +129,38 @@ class HipOps:
                                          _p(work), work.numel(), self._st()), "pg_nlml_grad")
 
     # -- prediction ---------------------------------------------------------------------------
-    def predict_mean_q(self, ks, minv, alpha, mean, q, work):
+    def predict_mean_q(self, ks, minv, alpha, mean, var, kss, work):
+        """mean = Ks^T alpha; var = kss - colsum((Minv Ks)^2) (var None: mean only)."""
+        q = var
         self._chk(ks, minv, alpha, mean, q, work)
         _lib.check(self.lib.pg_predict_mean_q(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(ks), ks.stride(0),
                                               _p(minv), minv.stride(0) if minv is not None else 0, _p(alpha),
-                                              _p(mean), _p(q), _p(work), self._st()), "pg_predict_mean_q")
+                                              _p(mean), _p(q), float(kss), _p(work), self._st()),
+                   "pg_predict_mean_q")
 
     def trmm_lower(self, minv, ks, v):
         self._chk(minv, ks, v)
         _lib.check(self.lib.pg_trmm_lower(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(minv), minv.stride(0),
                                           _p(ks), ks.stride(0), _p(v), v.stride(0), self._st()), "pg_trmm_lower")
 
-    def syrk_tn_sub(self, v, c):
+    def syrk_tn_sub(self, v, c, lower_only=True):
         self._chk(v, c)
         _lib.check(self.lib.pg_syrk_tn_sub(self.h, _code(v.dtype), c.shape[0], v.shape[0], _p(v), v.stride(0), _p(c),
-                                           c.stride(0), self._st()), "pg_syrk_tn_sub")
+                                           c.stride(0), int(lower_only), self._st()), "pg_syrk_tn_sub")
 
     # -- grBCM --------------------------------------------------------------------------------
-    def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out):
-        self._chk(mean_c, var_c, var_g, out)
+    def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out, beta=None, prec=None):
+        self._chk(mean_c, var_c, var_g, out, beta, prec)
         assert out.dtype == torch.float64 and out.shape[0] == 3
         _lib.check(self.lib.pg_grbcm_local_terms(self.h, _code(mean_c.dtype), mean_c.numel(), _p(mean_c), _p(var_c),
                                                  _p(var_g), int(is_first), int(accumulate), _p(out), out.stride(0),
-                                                 self._st()), "pg_grbcm_local_terms")
+                                                 _p(beta), _p(prec), self._st()), "pg_grbcm_local_terms")
 
-    def grbcm_finish(self, sums, mean_g, var_g, mean, var):
-        self._chk(sums, mean_g, var_g, mean, var)
+    def grbcm_finish(self, sums, mean_g, var_g, mean, var, beta0=None, prec0=None):
+        self._chk(sums, mean_g, var_g, mean, var, beta0, prec0)
         _lib.check(self.lib.pg_grbcm_finish(self.h, _code(mean_g.dtype), mean_g.numel(), _p(sums), sums.stride(0),
-                                            _p(mean_g), _p(var_g), _p(mean), _p(var), self._st()), "pg_grbcm_finish")
+                                            _p(mean_g), _p(var_g), _p(mean), _p(var), _p(beta0), _p(prec0),
+                                            self._st()), "pg_grbcm_finish")
 
     # -- raw GEMM core (tests, roofline micro-benchmark) ---------------------------------------
     def gemm_raw(self, variant, m, n, k, alpha, a, b, beta, c, tri=0, klo=0, khi=0):

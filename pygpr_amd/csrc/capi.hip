@@ -100,6 +100,14 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
                               lower_only, jitter, (float*)K, ldk, rows_pad, cols_pad));
 }
 
+int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
+                         int n, int d, void* dK, void* stream) {
+    NEED(h && hp && X && dK, "null pointer");
+    if (check_spec(spec, __func__)) return -1;
+    DISPATCH(dtype, pg_kgrad<double>(ST(stream), *spec, hp, (const double*)X, ldx, n, d, (double*)dK),
+             pg_kgrad<float>(ST(stream), *spec, hp, (const float*)X, ldx, n, d, (float*)dK));
+}
+
 long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize_impl(n); }
 
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
@@ -168,14 +176,14 @@ int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* h
 }
 
 int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv, long ldm,
-                      const void* alpha, void* mean, void* q, void* work, void* stream) {
+                      const void* alpha, void* mean, void* q, double kss, void* work, void* stream) {
     NEED(h && Ks && alpha && mean && work, "null pointer");
     NEED(!q || Minv, "variance needs Minv");
     DISPATCH(dtype,
              pg_predict_mean_q_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Ks, ldks, (const double*)Minv, ldm,
-                                         (const double*)alpha, (double*)mean, (double*)q, (double*)work),
+                                         (const double*)alpha, (double*)mean, (double*)q, kss, (double*)work),
              pg_predict_mean_q_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Ks, ldks, (const float*)Minv, ldm,
-                                        (const float*)alpha, (float*)mean, (float*)q, (float*)work));
+                                        (const float*)alpha, (float*)mean, (float*)q, kss, (float*)work));
 }
 
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks, long ldks,
@@ -188,31 +196,33 @@ int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv
                                     (float*)V, ldv));
 }
 
-int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc, void* stream) {
+int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc, int lower_only,
+                   void* stream) {
     NEED(h && V && C, "null pointer");
-    DISPATCH(dtype, pg_syrk_tn_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)V, ldv, (double*)C, ldc),
-             pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc));
+    DISPATCH(dtype, pg_syrk_tn_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)V, ldv, (double*)C, ldc, lower_only),
+             pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc, lower_only));
 }
 
 int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
-                         int is_first, int accumulate, double* out, long ldo, void* stream) {
+                         int is_first, int accumulate, double* out, long ldo, double* beta_out, double* prec_out,
+                         void* stream) {
     NEED(h && mean_c && var_c && var_g && out, "null pointer");
     NEED(ldo >= m, "ldo < m");
     DISPATCH(dtype,
              pg_grbcm_terms_t<double>(ST(stream), m, (const double*)mean_c, (const double*)var_c, (const double*)var_g,
-                                      is_first, accumulate, out, ldo),
+                                      is_first, accumulate, out, ldo, beta_out, prec_out),
              pg_grbcm_terms_t<float>(ST(stream), m, (const float*)mean_c, (const float*)var_c, (const float*)var_g,
-                                     is_first, accumulate, out, ldo));
+                                     is_first, accumulate, out, ldo, beta_out, prec_out));
 }
 
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
-                    void* mean, void* var, void* stream) {
+                    void* mean, void* var, double* beta0, double* prec0, void* stream) {
     NEED(h && sums && mean_g && var_g && mean && var, "null pointer");
     DISPATCH(dtype,
              pg_grbcm_finish_t<double>(ST(stream), m, sums, lds, (const double*)mean_g, (const double*)var_g, (double*)mean,
-                                       (double*)var),
+                                       (double*)var, beta0, prec0),
              pg_grbcm_finish_t<float>(ST(stream), m, sums, lds, (const float*)mean_g, (const float*)var_g, (float*)mean,
-                                      (float*)var));
+                                      (float*)var, beta0, prec0));
 }
 
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
 
     // XCD-aware tile order: blocks b, b+8, .. share one XCD's L2; give each XCD a contiguous run of
     // tiles (bijective for any grid size) so neighbouring tiles re-use operand panels from L2.
+    // Tiles with unequal K ranges (triangular operands) keep launch order instead: longest first and
+    // round-robin over the XCDs, which balances the work.
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int wg = (p.klo | p.khi) ? b : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
 
     int ti, tj;
     if (p.tri) {

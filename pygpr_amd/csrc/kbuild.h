@@ -10,3 +10,5 @@ template <typename T>
 int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,
                    const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork);
 long pg_nlml_grad_worksize_impl(int n, int nhp);
+template <typename T>
+int pg_kgrad(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, T* dK);

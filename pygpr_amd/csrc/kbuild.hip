@@ -143,6 +143,62 @@ template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, con
                               const float*, long, int, int, int, int, double, float*, long, int, int);
 
 // ------------------------------------------------------------------------------------------------
+// dK stack of the public Covar.kernel_and_grad (covar.py:64-81,169-206,247-269): dK[p][i][j] for
+// every hyper-parameter p.  Only the drop-in surface needs it; the NLML path never materialises it.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pg_kgrad_kernel(pg_covspec spec, const double* __restrict__ hp,
+                                                       const T* __restrict__ X, long ldx, int n, int d,
+                                                       T* __restrict__ dK, long slab) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= n || j >= n) return;
+    const long e = (long)i * n + j;
+    const T* xi = X + (long)i * ldx;
+    const T* xj = X + (long)j * ldx;
+    for (int cp = 0; cp < spec.ncomp; ++cp) {
+        const int o = spec.off[cp];
+        const double sg = hp[o];
+        T sq = (T)0;
+        for (int k = 0; k < d; ++k) {
+            const double l = hp[o + 1 + k];
+            const T df = xi[k] - xj[k];
+            sq += (T)(l * l) * df * df;
+        }
+        T kv, base, coef;
+        if (spec.kind[cp] == PG_KIND_RBF) {
+            kv = (T)(sg * sg) * exp(-sq);
+            base = kv;
+            coef = (T)-2;
+        } else {
+            const T s5 = (T)2.23606797749978969641;
+            const T rr = sqrt(sq), ex = exp(-s5 * rr);
+            kv = (T)(sg * sg) * ((T)1 + s5 * rr + (T)(5.0 / 3.0) * sq) * ex;
+            base = (T)(sg * sg) * ((T)1 + s5 * rr) * ex;
+            coef = (T)(-5.0 / 3.0);
+        }
+        dK[(long)o * slab + e] = kv * (T)(2.0 / sg);
+        for (int k = 0; k < d; ++k) {
+            const T df = xi[k] - xj[k];
+            dK[(long)(o + 1 + k) * slab + e] = coef * (T)hp[o + 1 + k] * df * df * base;
+        }
+    }
+    for (int q = 0; q < spec.nnoise; ++q)
+        dK[(long)spec.noise_off[q] * slab + e] = (i == j) ? (T)(2.0 * hp[spec.noise_off[q]]) : (T)0;
+}
+
+template <typename T>
+int pg_kgrad(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, T* dK) {
+    if (n <= 0 || d < 1 || d > PG_MAX_DIM) { pg_set_error("pg_kernel_grad_build: bad shape n=%d d=%d", n, d); return -2; }
+    hipLaunchKernelGGL(pg_kgrad_kernel<T>, dim3((n + 63) / 64, (n + 3) / 4), dim3(256), 0, st, spec, hp, X, ldx, n, d, dK,
+                       (long)n * n);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+template int pg_kgrad<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int, int, double*);
+template int pg_kgrad<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int, int, float*);
+
+// ------------------------------------------------------------------------------------------------
 // fused gradient contraction
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DMAX>

@@ -9,12 +9,13 @@ template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, lon
 template <typename T> int pg_nlml_value_t(hipStream_t, int n, const T* L, long ldl, const T* y, const T* alpha, double* out);
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx*, hipStream_t, int n, int m, const T* Ks, long ldks, const T* M, long ldm, const T* alpha,
-                        T* mean, T* q, T* work);
+                        T* mean, T* q, double kss, T* work);
 template <typename T> int pg_trmm_lower_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, const T* Ks, long ldks, T* V, long ldv);
-template <typename T> int pg_syrk_tn_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* V, long ldv, T* C, long ldc);
+template <typename T> int pg_syrk_tn_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only);
 template <typename T>
 int pg_grbcm_terms_t(hipStream_t, int m, const T* mean_c, const T* var_c, const T* var_g, int is_first, int accumulate,
-                     double* out, long ldo);
+                     double* out, long ldo, double* beta_out, double* prec_out);
 template <typename T>
-int pg_grbcm_finish_t(hipStream_t, int m, const double* sums, long lds, const T* mean_g, const T* var_g, T* mean, T* var);
+int pg_grbcm_finish_t(hipStream_t, int m, const double* sums, long lds, const T* mean_g, const T* var_g, T* mean, T* var,
+                      double* beta0, double* prec0);
 template <typename T> int pg_tril_t(hipStream_t, int n, T* A, long lda);

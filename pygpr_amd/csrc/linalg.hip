@@ -1,8 +1,9 @@
 // Host drivers of the blocked algorithms plus the small bandwidth-bound kernels around the MFMA core.
 //
-// potrf  : right-looking, NB = 256.  Each step: two 128x128 LDS leaves (leaf.hip) give L_kk and
-//          inv(L_kk); the panel solve is a GEMM against that inverse (B <- B inv(L_kk)^T, in place, one
-//          workgroup per 64 rows); the trailing update is one lower-tile SYRK on the MFMA core.
+// potrf  : two-level right-looking (outer 1024 / inner 256).  Each inner step: two 128x128 LDS leaves
+//          (leaf.hip) give L_kk and inv(L_kk); the panel solve is a GEMM against that inverse
+//          (B <- B inv(L_kk)^T, in place, one workgroup per 64 rows); the rest of the outer panel is
+//          updated with K = 256; the trailing matrix gets one lower-tile SYRK with K = 1024 per outer panel.
 // trtri  : Minv = L^-1 by recursive doubling over the diagonal: X21 = -X22 (L21 X11); all pairs of one
 //          level run in one batched launch; the product L21 X11 is parked (transposed) in the mirrored
 //          upper block, so no workspace is needed.
@@ -109,15 +110,15 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T* __restrict
     part[(long)rc * ldp + j] = (T)s;
 }
 
-// out[j] = sum_{rc >= rc0(j)} part[rc][j]
+// out[j] = a + b * sum_{rc >= rc0(j)} part[rc][j]
 template <typename T>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ part, long ldp, int nrc, int cols,
-                                                        T* __restrict__ out, int tri) {
+                                                        T* __restrict__ out, int tri, double a, double b) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cols) return;
     double s = 0.0;
     for (int rc = tri ? j / 256 : 0; rc < nrc; ++rc) s += (double)part[(long)rc * ldp + j];
-    out[j] = (T)s;
+    out[j] = (T)(a + b * s);
 }
 
 // y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 256-block (lower-triangular M)
@@ -154,11 +155,14 @@ __global__ __launch_bounds__(256) void nlml_value_kernel(const T* __restrict__ L
 template <typename T>
 __global__ __launch_bounds__(256) void grbcm_terms_kernel(const T* __restrict__ mean_c, const T* __restrict__ var_c,
                                                           const T* __restrict__ var_g, int m, int is_first,
-                                                          int accumulate, double* __restrict__ out, long ldo) {
+                                                          int accumulate, double* __restrict__ out, long ldo,
+                                                          double* __restrict__ beta_out, double* __restrict__ prec_out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     const double pc = 1.0 / (double)var_c[j], pg = 1.0 / (double)var_g[j];
     const double beta = is_first ? 1.0 : 0.5 * (log(pc) - log(pg));
+    if (beta_out) beta_out[j] = beta;
+    if (prec_out) prec_out[j] = pc;
     const double t0 = beta, t1 = beta * pc, t2 = beta * pc * (double)mean_c[j];
     if (accumulate) { out[j] += t0; out[ldo + j] += t1; out[2 * ldo + j] += t2; }
     else { out[j] = t0; out[ldo + j] = t1; out[2 * ldo + j] = t2; }
@@ -167,11 +171,14 @@ __global__ __launch_bounds__(256) void grbcm_terms_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void grbcm_finish_kernel(const double* __restrict__ sums, long lds, const T* __restrict__ mean_g,
                                                            const T* __restrict__ var_g, int m, T* __restrict__ mean,
-                                                           T* __restrict__ var) {
+                                                           T* __restrict__ var, double* __restrict__ beta0,
+                                                           double* __restrict__ prec0) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     const double pg = 1.0 / (double)var_g[j];
     const double b0 = 1.0 - sums[j];
+    if (beta0) beta0[j] = b0;
+    if (prec0) prec0[j] = pg;
     const double v = 1.0 / (sums[lds + j] + b0 * pg);
     var[j] = (T)v;
     mean[j] = (T)(v * (sums[2 * lds + j] + b0 * pg * (double)mean_g[j]));
@@ -196,6 +203,37 @@ template <typename T> static GemmP<T> gp0() {
 
 long pg_potrf_worksize_impl(int n) { return (long)n * NB + 128 * 128; }
 
+// Factor the 256x256 diagonal block at k0 (two LDS leaves + three single-tile GEMMs) and assemble its inverse.
+template <typename T>
+static int diag_block(pg_ctx* ctx, hipStream_t st, T* A, long lda, int k0, T* inv, T* scratch, int* info) {
+    T* Akk = A + (long)k0 * lda + k0;
+    T* A21 = Akk + 128 * lda;
+    T* A22 = A21 + 128;
+    T* inv22 = inv + 128 * NB + 128;
+    int rc;
+    if ((rc = pg_leaf<T>(st, Akk, lda, inv, NB, info, k0))) return rc;
+    GemmP<T> p = gp0<T>();
+    p.info = info;
+    // A21 <- A21 inv11^T
+    p.M = p.N = p.K = 128; p.A = A21; p.lda = lda; p.B = inv; p.ldb = NB; p.C = A21; p.ldc = lda; p.khi = 2;
+    if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+    // A22 -= A21 A21^T
+    p.khi = 0; p.B = A21; p.ldb = lda; p.C = A22; p.alpha = (T)-1; p.beta = (T)1;
+    if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+    if ((rc = pg_leaf<T>(st, A22, lda, inv22, NB, info, k0 + 128))) return rc;
+    // inv21 = -inv22 (L21 inv11): scratch = (L21 inv11)^T = inv11^T L21^T, then NT against it
+    p = gp0<T>(); p.info = info;
+    p.M = p.N = p.K = 128; p.A = inv; p.lda = NB; p.B = A21; p.ldb = lda; p.C = scratch; p.ldc = 128; p.klo = 1;
+    if ((rc = pg_gemm<T>(ctx, st, GEMM_TT_128, p))) return rc;
+    p.klo = 0; p.khi = 1; p.A = inv22; p.lda = NB; p.B = scratch; p.ldb = 128; p.C = inv + 128 * NB; p.ldc = NB;
+    p.alpha = (T)-1;
+    return pg_gemm<T>(ctx, st, GEMM_NT_128, p);
+}
+
+// Two-level right-looking Cholesky: inner steps of NB = 256 columns (diagonal block, panel solve against its
+// inverse, update of the REST OF THE OUTER PANEL only), and one lower-tile SYRK with K = NBO per outer panel, so
+// the big trailing update re-reads/re-writes C once per NBO columns instead of once per 256.
+#define NBO 1024
 template <typename T>
 int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info) {
     if (n <= 0 || n % NB) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, NB); return -2; }
@@ -203,37 +241,31 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     PG_CHECK(hipMemsetAsync(invD, 0, (size_t)pg_potrf_worksize_impl(n) * sizeof(T), st));
     T* scratch = invD + (long)n * NB;   // 128 x 128
     int rc;
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        T* Akk = A + (long)k0 * lda + k0;
-        T* A21 = Akk + 128 * lda;
-        T* A22 = A21 + 128;
-        T* inv = invD + (long)(k0 / NB) * NB * NB;
-        T* inv22 = inv + 128 * NB + 128;
-        if ((rc = pg_leaf<T>(st, Akk, lda, inv, NB, info, k0))) return rc;
-        GemmP<T> p = gp0<T>();
-        p.info = info;
-        // A21 <- A21 inv11^T
-        p.M = p.N = p.K = 128; p.A = A21; p.lda = lda; p.B = inv; p.ldb = NB; p.C = A21; p.ldc = lda; p.khi = 2;
-        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
-        // A22 -= A21 A21^T
-        p.khi = 0; p.B = A21; p.ldb = lda; p.C = A22; p.alpha = (T)-1; p.beta = (T)1;
-        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
-        if ((rc = pg_leaf<T>(st, A22, lda, inv22, NB, info, k0 + 128))) return rc;
-        // inv21 = -inv22 (L21 inv11): scratch = (L21 inv11)^T = inv11^T L21^T, then NT against it
-        p = gp0<T>(); p.info = info;
-        p.M = p.N = p.K = 128; p.A = inv; p.lda = NB; p.B = A21; p.ldb = lda; p.C = scratch; p.ldc = 128; p.klo = 1;
-        if ((rc = pg_gemm<T>(ctx, st, GEMM_TT_128, p))) return rc;
-        p.klo = 0; p.khi = 1; p.A = inv22; p.lda = NB; p.B = scratch; p.ldb = 128; p.C = inv + 128 * NB; p.ldc = NB;
-        p.alpha = (T)-1;
-        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
-        const int m = n - k0 - NB;
-        if (m > 0) {
-            T* P = A + (long)(k0 + NB) * lda + k0;
-            p = gp0<T>(); p.info = info;
+    for (int o0 = 0; o0 < n; o0 += NBO) {
+        const int oend = std::min(n, o0 + NBO);
+        for (int k0 = o0; k0 < oend; k0 += NB) {
+            T* inv = invD + (long)(k0 / NB) * NB * NB;
+            if ((rc = diag_block<T>(ctx, st, A, lda, k0, inv, scratch, info))) return rc;
+            const int m = n - k0 - NB;
+            if (m <= 0) continue;
+            T* P = A + (long)(k0 + NB) * lda + k0;          // rows below the diagonal block, 256 columns
+            GemmP<T> p = gp0<T>(); p.info = info;
             p.M = m; p.N = NB; p.K = NB; p.A = P; p.lda = lda; p.B = inv; p.ldb = NB; p.C = P; p.ldc = lda; p.khi = 2;
             if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_RP, p))) return rc;
-            p = gp0<T>(); p.info = info;
-            p.M = p.N = m; p.K = NB; p.A = P; p.lda = lda; p.B = P; p.ldb = lda; p.C = P + NB; p.ldc = lda;
+            const int w = oend - k0 - NB;                   // columns of the outer panel still to be factored
+            if (w > 0) {
+                p = gp0<T>(); p.info = info;
+                p.M = m; p.N = w; p.K = NB; p.A = P; p.lda = lda; p.B = P; p.ldb = lda; p.C = P + NB; p.ldc = lda;
+                p.alpha = (T)-1; p.beta = (T)1;
+                if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+            }
+        }
+        const int m = n - oend;
+        if (m > 0) {
+            T* P = A + (long)oend * lda + o0;               // m x (oend - o0): final L values of this outer panel
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = p.N = m; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
+            p.C = A + (long)oend * lda + oend; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
             if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
         }
@@ -320,7 +352,7 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
         hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((n + 15) / 16), dim3(256), 0, st, M, ldm, n, x, y);
     } else {
         hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(n / 256, n / 256), dim3(256), 0, st, M, ldm, x, work, (long)n, 1);
-        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256), dim3(256), 0, st, work, (long)n, n / 256, n, y, 1);
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256), dim3(256), 0, st, work, (long)n, n / 256, n, y, 1, 0.0, 1.0);
     }
     LAUNCH_CHECK();
     return 0;
@@ -335,10 +367,10 @@ int pg_nlml_value_t(hipStream_t st, int n, const T* L, long ldl, const T* y, con
 
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, long ldks, const T* M, long ldm,
-                        const T* alpha, T* mean, T* q, T* work) {
+                        const T* alpha, T* mean, T* q, double kss, T* work) {
     if (n % NB || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
     hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(m / 256, n / 256), dim3(256), 0, st, Ks, ldks, alpha, work, (long)m, 0);
-    hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 256, m, mean, 0);
+    hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 256, m, mean, 0, 0.0, 1.0);
     LAUNCH_CHECK();
     if (q) {
         GemmP<T> p = gp0<T>();
@@ -346,7 +378,7 @@ int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, 
         p.part = work; p.ldp = m;
         int rc = pg_gemm<T>(ctx, st, GEMM_NN_128_SS, p);
         if (rc) return rc;
-        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0);
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0, kss, -1.0);
         LAUNCH_CHECK();
     }
     return 0;
@@ -361,25 +393,27 @@ int pg_trmm_lower_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* M, long 
 }
 
 template <typename T>
-int pg_syrk_tn_sub_t(pg_ctx* ctx, hipStream_t st, int m, int n, const T* V, long ldv, T* C, long ldc) {
+int pg_syrk_tn_sub_t(pg_ctx* ctx, hipStream_t st, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only) {
     if (n % 16 || m % 128) { pg_set_error("pg_syrk_tn_sub: m_pad=%d n_pad=%d not aligned", m, n); return -2; }
     GemmP<T> p = gp0<T>();
     p.M = p.N = m; p.K = n; p.A = V; p.lda = ldv; p.B = V; p.ldb = ldv; p.C = C; p.ldc = ldc;
-    p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
+    p.alpha = (T)-1; p.beta = (T)1; p.tri = lower_only ? 1 : 0;
     return pg_gemm<T>(ctx, st, GEMM_TN_128, p);
 }
 
 template <typename T>
 int pg_grbcm_terms_t(hipStream_t st, int m, const T* mean_c, const T* var_c, const T* var_g, int is_first, int accumulate,
-                     double* out, long ldo) {
+                     double* out, long ldo, double* beta_out, double* prec_out) {
     hipLaunchKernelGGL(grbcm_terms_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, mean_c, var_c, var_g, m, is_first,
-                       accumulate, out, ldo);
+                       accumulate, out, ldo, beta_out, prec_out);
     LAUNCH_CHECK();
     return 0;
 }
 template <typename T>
-int pg_grbcm_finish_t(hipStream_t st, int m, const double* sums, long lds, const T* mean_g, const T* var_g, T* mean, T* var) {
-    hipLaunchKernelGGL(grbcm_finish_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, sums, lds, mean_g, var_g, m, mean, var);
+int pg_grbcm_finish_t(hipStream_t st, int m, const double* sums, long lds, const T* mean_g, const T* var_g, T* mean, T* var,
+                      double* beta0, double* prec0) {
+    hipLaunchKernelGGL(grbcm_finish_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, sums, lds, mean_g, var_g, m, mean, var,
+                       beta0, prec0);
     LAUNCH_CHECK();
     return 0;
 }
@@ -398,11 +432,13 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \
-                                        T*, T*);                                                                       \
+                                        T*, double, T*);                                                               \
     template int pg_trmm_lower_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, T*, long);         \
-    template int pg_syrk_tn_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, T*, long);                        \
-    template int pg_grbcm_terms_t<T>(hipStream_t, int, const T*, const T*, const T*, int, int, double*, long);         \
-    template int pg_grbcm_finish_t<T>(hipStream_t, int, const double*, long, const T*, const T*, T*, T*);              \
+    template int pg_syrk_tn_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, T*, long, int);                     \
+    template int pg_grbcm_terms_t<T>(hipStream_t, int, const T*, const T*, const T*, int, int, double*, long, double*, \
+                                     double*);                                                                         \
+    template int pg_grbcm_finish_t<T>(hipStream_t, int, const double*, long, const T*, const T*, T*, T*, double*,     \
+                                      double*);                                                                        \
     template int pg_tril_t<T>(hipStream_t, int, T*, long);
 INST(double)
 INST(float)

@@ -1,0 +1,284 @@
+"""GP models with PyGPR's class surface (reference: PyGPR/gpr.py) on the MI355X.
+
+`Exact_GP.update` = covariance build + 1e-7 jitter + Cholesky + alpha = K^-1 y (gpr.py:65-74);
+`predict` = K* build, mean K* alpha, and either the diagonal predictive variance
+diag(K**) - rowsum(K* o (K^-1 K*^T)^T) (gpr.py:96-106) or the full covariance (gpr.py:108-120).
+All state lives on the GPU in padded buffers (n rounded up to 256, identity in the padding); the
+leading expert dimension of the reference's batched models is a host loop over per-expert buffers.
+
+Differences a caller can observe:
+  * the triangular solves against K* use the explicit inverse factor L^-1 (cached per update), so the
+    variance is a GEMM with a fused column-sum-of-squares epilogue instead of `cholesky_solve`
+  * K** is never built for var="diag": its diagonal is sum sigma_c^2 + sum sigma_n^2 analytically
+  * assigning `model.x` / `model.y` marks the model dirty (the reference keeps a stale factor there)
+  * `krn`, `krnchd`, `wt` are read-only views materialised on access
+"""
+from typing import Sequence
+
+import torch
+from torch import Tensor
+
+from ._ops import JITTER, get_ops, pad_to
+from .covar import Covar, layout, spec_of
+
+_CHUNK = 8192  # test points per device batch
+
+
+def _lin_alg_error(info: int):
+    return torch.linalg.LinAlgError(
+        "cholesky: The factorization could not be completed because the input is not positive-definite "
+        "(the leading minor of order %d is not positive-definite)." % info)
+
+
+class GPR:
+    """Base class for Gaussian process regression models (PyGPR/gpr.py:13-43)."""
+
+    def __init__(self, x: Tensor, y: Tensor, cov: Covar) -> None:
+        self._x: Tensor = x
+        self._y: Tensor = y
+        self.cov = cov
+        self.params: Tensor = NotImplemented
+        self.need_upd: bool = True
+        return None
+
+    @property
+    def x(self) -> Tensor:
+        return self._x
+
+    @x.setter
+    def x(self, value: Tensor) -> None:
+        self._x = value
+        self._data_changed()
+
+    @property
+    def y(self) -> Tensor:
+        return self._y
+
+    @y.setter
+    def y(self, value: Tensor) -> None:
+        self._y = value
+        self._data_changed()
+
+    def _data_changed(self) -> None:
+        self.need_upd = True
+
+    def set_params(self, params: Tensor) -> None:
+        self.params = torch.clone(params)
+        self.need_upd = True
+        return None
+
+    def update(self) -> None:
+        raise NotImplementedError
+
+    def predict(self, xp: Tensor, var: str) -> Sequence[Tensor]:
+        raise NotImplementedError
+
+    def predict_var(self, xp: Tensor, **kwrgs: Tensor) -> Tensor:
+        raise NotImplementedError
+
+    def predict_covar(self, xp: Tensor, **kwargs: Tensor) -> Tensor:
+        raise NotImplementedError
+
+
+class _Expert:
+    """Device state of one expert."""
+
+    __slots__ = ("x", "y", "n", "n_pad", "chol", "invd", "alpha", "minv", "hp", "info")
+
+    def __init__(self):
+        self.chol = self.invd = self.alpha = self.minv = self.hp = self.info = None
+
+
+class Exact_GP(GPR):
+    """Exact GP model (PyGPR/gpr.py:46-120); x [(nc), n, d], y [(nc), n], params [(nc), nhp]."""
+
+    def __init__(self, x: Tensor, y: Tensor, cov: Covar) -> None:
+        super().__init__(x, y, cov)
+        self.params: Tensor = cov.init_params(x)
+        self._experts = None
+        self.need_upd: bool = True
+        return None
+
+    # ---- device residency -------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self._x.dtype if self._x.dtype == torch.float32 else torch.float64
+
+    @property
+    def batched(self) -> bool:
+        return self._x.dim() > 2
+
+    def _data_changed(self) -> None:
+        self._experts = None
+        self.need_upd = True
+
+    def _device_experts(self):
+        """Upload x / y once (padded y), one _Expert per leading index."""
+        if self._experts is None:
+            ops = get_ops()
+            xb = self._x.reshape(-1, self._x.shape[-2], self._x.shape[-1])
+            yb = self._y.reshape(-1, self._y.shape[-1])
+            ex = []
+            for b in range(xb.shape[0]):
+                e = _Expert()
+                e.n = xb.shape[1]
+                e.n_pad = pad_to(e.n)
+                e.x = ops.to_device(xb[b], self.dtype)
+                e.y = ops.zeros(e.n_pad, dtype=self.dtype)
+                e.y[: e.n] = ops.to_device(yb[b % yb.shape[0]], self.dtype)
+                ex.append(e)
+            self._experts = ex
+        return self._experts
+
+    def _hp_rows(self):
+        nhp = self.params.shape[-1]
+        return self.params.reshape(-1, nhp).to(torch.float64)
+
+    # ---- the path ---------------------------------------------------------------------------
+    def update(self) -> None:
+        if self.need_upd:
+            ops = get_ops()
+            experts = self._device_experts()
+            hp_rows = self._hp_rows()
+            spec, nhp = spec_of(self.cov, self._x.shape[-1])
+            assert hp_rows.shape[-1] == nhp
+            for b, e in enumerate(experts):
+                e.hp = ops.to_device(hp_rows[b % hp_rows.shape[0]], torch.float64)
+                if e.chol is None:
+                    e.chol = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+                    e.invd = ops.potrf_workspace(e.n_pad, self.dtype)
+                    e.alpha = ops.empty(e.n_pad, dtype=self.dtype)
+                    e.info = torch.zeros(1, dtype=torch.int32, device=ops.device)
+                e.minv = None
+                ops.kernel_build(spec, e.hp, e.x, None, e.chol, lower_only=True, jitter=JITTER)
+                ops.potrf(e.chol, e.invd, e.info)
+                ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
+            for e in experts:   # one sync point after everything is enqueued
+                info = int(e.info.item())
+                if info:
+                    raise _lin_alg_error(info)
+            self.need_upd = False
+        return None
+
+    def _minv(self, e):
+        if e.minv is None:
+            ops = get_ops()
+            e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+            ops.trtri(e.chol, e.invd, e.minv)
+        return e.minv
+
+    def _kss_diag(self, b: int) -> float:
+        """diag of cov.kernel(params, xp): sum sigma_c^2 + sum sigma_n^2 (White_noise sees xp=None,
+        gpr.py:98), no jitter."""
+        _, offs, noise, _ = layout(self.cov, self._x.shape[-1])
+        hp = self._hp_rows()
+        row = hp[b % hp.shape[0]]
+        return float(sum(row[o] ** 2 for o in offs) + sum(row[o] ** 2 for o in noise))
+
+    def _predict_expert(self, b, e, xpd, want):
+        ops = get_ops()
+        spec, _ = spec_of(self.cov, self._x.shape[-1])
+        m = xpd.shape[0]
+        mean = ops.empty(m, dtype=self.dtype)
+        var = ops.empty(m, dtype=self.dtype) if want == "diag" else None
+        if want == "full":
+            cov = self._predict_full(e, spec, xpd)
+        for s in range(0, m, _CHUNK):
+            xq = xpd[s: s + _CHUNK]
+            mc = xq.shape[0]
+            m_pad = pad_to(mc)
+            ks = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
+            ops.kernel_build(spec, e.hp, e.x, xq, ks)
+            mu = ops.empty(m_pad, dtype=self.dtype)
+            vq = ops.empty(m_pad, dtype=self.dtype) if want == "diag" else None
+            work = ops.empty((e.n_pad // 64) * m_pad, dtype=self.dtype)
+            ops.predict_mean_q(ks, self._minv(e) if want == "diag" else None, e.alpha, mu, vq,
+                               self._kss_diag(b), work)
+            mean[s: s + mc] = mu[:mc]
+            if want == "diag":
+                var[s: s + mc] = vq[:mc]
+        if want == "diag":
+            return mean, var
+        if want == "full":
+            return mean, cov
+        return mean, None
+
+    def _predict_full(self, e, spec, xpd):
+        """K** - K* K^-1 K*^T = K** - V^T V with V = L^-1 K*^T (gpr.py:108-120)."""
+        ops = get_ops()
+        m = xpd.shape[0]
+        m_pad = pad_to(m)
+        ks = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
+        ops.kernel_build(spec, e.hp, e.x, xpd, ks)
+        v = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
+        ops.trmm_lower(self._minv(e), ks, v)
+        c = ops.empty(m_pad, m_pad, dtype=self.dtype)
+        ops.kernel_build(spec, e.hp, xpd, None, c)      # K** incl. sigma_n^2, padding = identity
+        ops.syrk_tn_sub(v, c, lower_only=False)
+        return c[:m, :m]
+
+    def _predict_device(self, xpd, want):
+        """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points."""
+        self.update()
+        means, covs = [], []
+        for b, e in enumerate(self._experts):
+            mu, cv = self._predict_expert(b, e, xpd, want)
+            means.append(mu)
+            covs.append(cv)
+        return means, covs
+
+    def predict(self, xp: Tensor, var: str = "full") -> Sequence[Tensor]:
+        ops = get_ops()
+        want = var if var in ("full", "diag") else "none"
+        xpd = ops.to_device(xp.reshape(-1, xp.shape[-1]), self.dtype)
+        means, covs = self._predict_device(xpd, want)
+        ys = torch.stack(means).squeeze().to(xp.device)   # squeeze_(): drops every size-1 dim (gpr.py:87)
+        if want == "none":
+            covars = NotImplemented
+        elif self.batched:
+            covars = torch.stack(covs).to(xp.device)
+        else:
+            covars = covs[0].contiguous().to(xp.device)
+        return [ys, covars]
+
+    def predict_var(self, xp: Tensor, **kwargs: Tensor) -> Tensor:
+        return self.predict(xp, var="diag")[1]
+
+    def predict_covar(self, xp: Tensor, **kwargs: Tensor) -> Tensor:
+        return self.predict(xp, var="full")[1]
+
+    # ---- reference attributes, materialised on access ------------------------------------------
+    def _stack(self, ts):
+        out = torch.stack(ts) if self.batched else ts[0]
+        return out.contiguous().to(self._x.device)
+
+    @property
+    def krn(self) -> Tensor:
+        """K + 1e-7 I as `Exact_GP.krn` holds it after update (gpr.py:67-68); rebuilt on access."""
+        self.update()
+        ops = get_ops()
+        spec, _ = spec_of(self.cov, self._x.shape[-1])
+        outs = []
+        for e in self._experts:
+            k = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+            ops.kernel_build(spec, e.hp, e.x, None, k, jitter=JITTER)
+            outs.append(k[: e.n, : e.n])
+        return self._stack(outs)
+
+    @property
+    def krnchd(self) -> Tensor:
+        """Lower Cholesky factor with a zero upper triangle, like tc.cholesky (gpr.py:69)."""
+        self.update()
+        ops = get_ops()
+        outs = []
+        for e in self._experts:
+            c = e.chol.clone()
+            ops.tril(c, e.n_pad)
+            outs.append(c[: e.n, : e.n])
+        return self._stack(outs)
+
+    @property
+    def wt(self) -> Tensor:
+        """alpha = K^-1 y (gpr.py:70-72)."""
+        self.update()
+        return self._stack([e.alpha[: e.n] for e in self._experts])

@@ -1,0 +1,180 @@
+"""Generalised robust Bayesian committee machine with PyGPR's surface (reference: PyGPR/gr_bcm.py).
+
+`GRBCM(xl, yl, xg, yg, cov)` builds the global expert `gpg` on the communication set and the local
+experts `gpl`, each on (global set U its own shard) (gr_bcm.py:12-34); `predict` aggregates
+(gr_bcm.py:116-155):
+
+    prec_c = 1/var_c,  beta_c = 1/2 (log prec_c - log prec_0) (c >= 2),  beta_1 = 1,
+    beta_0 = 1 - sum_c beta_c,  var = 1 / sum beta prec,  mu = var sum beta prec mu
+
+Multi-GPU (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI): with
+`distributed=True` rank r owns a contiguous block of local experts and keeps only those in `gpl`; every
+rank holds the small global expert.  Factorisations and predictions need no communication; per test
+batch there is ONE all-reduce(sum) of the [3, m] fp64 buffer (sum beta_c, sum beta_c prec_c,
+sum beta_c prec_c mu_c).  `GRBCM_MLE` is the shared-hyper-parameter training objective sum_c NLML_c (one
+all-reduce of [1 + nhp]); it replaces the reference's dead `GRBCM.train` (gr_bcm.py:36-97 raises).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._ops import get_ops
+from .gpr import GPR, Exact_GP
+from .loss import MLE, Loss
+
+
+def _dist_on(flag):
+    if flag is None:
+        return False
+    return bool(flag) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def expert_block(nc, rank, world):
+    """Contiguous block of local experts owned by `rank`."""
+    per = (nc + world - 1) // world
+    lo = min(rank * per, nc)
+    return lo, min(lo + per, nc)
+
+
+def _all_reduce_sum(t, group=None):
+    """Sum a small tensor over ranks; NCCL/RCCL needs device memory, gloo takes host memory."""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class GRBCM(GPR):
+    def __init__(self, xl, yl, xg, yg, cov, hp=None, distributed=None, group=None, **kargs):
+        nc, nls = xl.shape[0], xl.shape[1]
+        ng, dim = xg.shape[0], xg.shape[1]
+        self.distributed = _dist_on(distributed)
+        self.group = group
+        if self.distributed:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self.lo, self.hi = expert_block(nc, self.rank, self.world)
+
+        xls, yls = xl[self.lo: self.hi], yl[self.lo: self.hi]
+        nloc = self.hi - self.lo
+        x = torch.cat((xg.unsqueeze(0).expand(nloc, ng, dim), xls), dim=1)   # gr_bcm.py:19-26
+        y = torch.cat((yg.unsqueeze(0).expand(nloc, ng), yls), dim=1)
+
+        self.cov = cov
+        self.gpg = Exact_GP(xg, yg, cov)                                    # gr_bcm.py:28
+        self.gpl = Exact_GP(x, y, cov) if nloc else None                    # gr_bcm.py:29 (owned experts)
+
+        self.nc = nc
+        self.nsc = nls
+        self.ng = ng
+        self.dim = dim
+        self.beta = NotImplemented
+        self.prec = NotImplemented
+
+    def set_local_params(self, params_all):
+        """params_all [nc, nhp] (or [nhp], shared): keep this rank's rows."""
+        if self.gpl is None:
+            return
+        if params_all.dim() == 1:
+            self.gpl.set_params(params_all.unsqueeze(0).expand(self.hi - self.lo, -1).contiguous())
+        else:
+            self.gpl.set_params(params_all[self.lo: self.hi])
+
+    # ---- aggregation ------------------------------------------------------------------------
+    def _aggregate_device(self, mean_g, var_g, means_l, vars_l):
+        """Device tensors in, device tensors out.  beta/prec rows: [global, owned local experts...]."""
+        ops = get_ops()
+        m = mean_g.numel()
+        nloc = len(means_l)
+        sums = ops.zeros(3, m, dtype=torch.float64)
+        beta = ops.empty(nloc + 1, m, dtype=torch.float64)
+        prec = ops.empty(nloc + 1, m, dtype=torch.float64)
+        for c in range(nloc):
+            ops.grbcm_local_terms(means_l[c], vars_l[c], var_g, (self.lo + c) == 0, True, sums,
+                                  beta[c + 1], prec[c + 1])
+        if self.distributed:
+            _all_reduce_sum(sums, self.group)
+        mean, var = ops.empty(m, dtype=mean_g.dtype), ops.empty(m, dtype=mean_g.dtype)
+        ops.grbcm_finish(sums, mean_g, var_g, mean, var, beta[0], prec[0])
+        self.beta, self.prec = beta, prec
+        return mean, var
+
+    def aggregate(self, ys_g, covars_g, ys_l, covars_l, var="diag"):
+        """GRBCM.aggregate (gr_bcm.py:116-149) on tensors shaped like Exact_GP.predict's outputs."""
+        if var != "diag":
+            raise NotImplementedError("full-covariance aggregation (gr_bcm.py:99-114) is not on the device path yet")
+        ops = get_ops()
+        dt = ys_g.dtype
+        mg, vg = ops.to_device(ys_g.reshape(-1), dt), ops.to_device(covars_g.reshape(-1), dt)
+        ml = ops.to_device(ys_l.reshape(-1, mg.numel()), dt)
+        vl = ops.to_device(covars_l.reshape(-1, mg.numel()), dt)
+        mean, var_ = self._aggregate_device(mg, vg, list(ml), list(vl))
+        self.beta, self.prec = self.beta.to(ys_g.device), self.prec.to(ys_g.device)
+        return mean.to(ys_g.device), var_.to(ys_g.device)
+
+    def predict(self, xs, var="diag"):
+        if var != "diag":
+            raise NotImplementedError("GRBCM.predict(var='full') (gr_bcm.py:99-114) is not on the device path yet")
+        ops = get_ops()
+        xsd = ops.to_device(xs.reshape(-1, xs.shape[-1]), self.gpg.dtype)
+        mg, vg = self.gpg._predict_device(xsd, "diag")
+        if self.gpl is not None:
+            ml, vl = self.gpl._predict_device(xsd, "diag")
+        else:
+            ml, vl = [], []
+        mean, var_ = self._aggregate_device(mg[0], vg[0], ml, vl)
+        self.beta, self.prec = self.beta.to(xs.device), self.prec.to(xs.device)
+        return mean.to(xs.device), var_.to(xs.device)
+
+
+class GRBCM_MLE(Loss):
+    """Shared-hyper-parameter objective sum_c NLML_c over the local experts of a GRBCM, with its
+    gradient: per-expert evaluations are independent (loss.py path); ranks exchange one [1 + nhp]
+    all-reduce.  Works with CG / get_learn_rate like any Loss."""
+
+    def __init__(self, model: GRBCM) -> None:
+        super().__init__(model)
+        self._mle = MLE(model.gpl) if model.gpl is not None else None
+
+    def _reduce(self, vec):
+        g = self.model
+        if g.distributed:
+            if dist.get_backend(g.group) == "gloo":
+                t = torch.from_numpy(vec)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g.group)
+            else:
+                t = get_ops().to_device(torch.from_numpy(vec))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=g.group)
+                vec = t.cpu().numpy()
+        return vec
+
+    def _local(self, params, want_grad):
+        nhp = np.asarray(params).shape[-1]
+        vec = np.zeros(1 + nhp)
+        if self._mle is not None:
+            nloc = self.model.hi - self.model.lo
+            rows = np.broadcast_to(np.asarray(params, dtype=np.float64), (nloc, nhp))
+            loss, grad = self._mle._evaluate(rows, want_grad)
+            vec[0] = np.sum(loss)
+            if want_grad:
+                vec[1:] = np.sum(grad, axis=0)
+        return self._reduce(vec)
+
+    def loss(self, params):
+        vec = self._local(params, False)
+        self.loss_value = np.array(vec[0])
+        return self.loss_value
+
+    def grad(self, params):
+        vec = self._local(params, True)
+        self.grad_value = vec[1:].copy()
+        return self.grad_value
+
+    def loss_and_grad(self, params):
+        vec = self._local(params, True)
+        self.loss_value, self.grad_value = np.array(vec[0]), vec[1:].copy()
+        return (self.loss_value, self.grad_value)

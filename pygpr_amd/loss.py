@@ -1,0 +1,124 @@
+"""Model-selection loss with PyGPR's surface (reference: PyGPR/loss.py) on the MI355X.
+
+    NLML          = 1/2 y^T a + sum_i log L_ii + n/2 log 2pi          (loss.py:47-49, 107-109)
+    dNLML/dtheta_k = -1/2 (a^T dK_k a - tr(K^-1 dK_k))                 (loss.py:116-121)
+
+The reference materialises dK[nhp,n,n] and runs `cholesky_solve` on it (n^3/3 + 2 nhp n^3 flop).  Here
+one evaluation is: covariance build (lower tiles) -> blocked Cholesky -> L^-1 -> alpha = L^-T (L^-1 y)
+-> K^-1 = L^-T L^-1 -> fused contraction 1/2 sum (K^-1 - a a^T) o dK_k with dK recomputed from the
+point tiles -- n^3 flop in MFMA GEMMs, two n x n device buffers, one [1 + nhp] transfer back.
+`MLE.*` take and return host NumPy fp64 exactly like the reference (scipy drives them).
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+from numpy import ndarray
+
+from ._ops import JITTER, get_ops
+from .covar import spec_of
+from .gpr import GPR, _lin_alg_error
+
+
+class Loss():
+    """Base class for cost functions for GP model selection (PyGPR/loss.py:10-28)."""
+
+    def __init__(self, model: GPR) -> None:
+        self.model: GPR = model
+        self.loss_value: float = NotImplemented
+        self.grad_value: ndarray = NotImplemented
+        return None
+
+    def loss(self, params: ndarray) -> float:
+        raise NotImplementedError
+
+    def grad(self, params: ndarray) -> ndarray:
+        raise NotImplementedError
+
+    def loss_and_grad(self, params: ndarray) -> Tuple[float, ndarray]:
+        raise NotImplementedError
+
+
+class MLE(Loss):
+    """Negative log marginal likelihood of the hyper-parameters (PyGPR/loss.py:31-128)."""
+
+    def __init__(self, model: GPR) -> None:
+        super().__init__(model)
+        self._buf = {}
+
+    def _buffers(self, n_pad, dtype, nhp, n):
+        key = (n_pad, dtype, nhp, n)
+        if self._buf.get("key") != key:
+            ops = get_ops()
+            self._buf = {
+                "key": key,
+                "a": ops.empty(n_pad, n_pad, dtype=dtype),       # K -> L -> K^-1
+                "m": None,                                         # L^-1 (gradient evaluations only)
+                "invd": ops.potrf_workspace(n_pad, dtype),
+                "info": torch.zeros(1, dtype=torch.int32, device=ops.device),
+                "alpha": ops.empty(n_pad, dtype=dtype),
+                "u": ops.empty(n_pad, dtype=dtype),
+                "vwork": ops.empty((n_pad // 256) * n_pad, dtype=dtype),
+                "gwork": ops.empty(ops.nlml_grad_worksize(n, nhp), dtype=torch.float64),
+                "out": ops.zeros(1 + nhp, dtype=torch.float64),
+            }
+        return self._buf
+
+    def _evaluate(self, params: ndarray, want_grad: bool):
+        ops = get_ops()
+        model = self.model
+        d = model.x.shape[-1]
+        spec, nhp = spec_of(model.cov, d)
+        p = np.asarray(params, dtype=np.float64)
+        assert p.shape[-1] == nhp  # covar.py:52,66
+        rows = p.reshape(-1, nhp)
+        experts = model._device_experts()
+        nb = max(len(experts), rows.shape[0])
+        losses = np.empty(nb)
+        grads = np.empty((nb, nhp))
+        for b in range(nb):
+            e = experts[b % len(experts)]
+            buf = self._buffers(e.n_pad, model.dtype, nhp, e.n)
+            hp = ops.to_device(torch.from_numpy(np.ascontiguousarray(rows[b % rows.shape[0]])), torch.float64)
+            a, out = buf["a"], buf["out"]
+            ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
+            ops.potrf(a, buf["invd"], buf["info"])
+            if want_grad:
+                if buf["m"] is None:
+                    buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
+                m = buf["m"]
+                ops.trtri(a, buf["invd"], m)
+                ops.trmv(m, e.y, buf["u"], 0)                       # u = L^-1 y
+                ops.trmv(m, buf["u"], buf["alpha"], 1, buf["vwork"])  # alpha = L^-T u
+                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
+                ops.lauum(m, a)                                     # a <- K^-1 (lower)
+                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
+            else:
+                ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
+                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
+            res = out.cpu().numpy()                                   # the one sync + transfer
+            info = int(buf["info"].item())
+            if info:
+                raise _lin_alg_error(info)
+            losses[b] = res[0]
+            grads[b] = res[1:]
+        batched = p.ndim > 1 or model.x.dim() > 2
+        loss = losses.copy() if batched else np.array(losses[0])
+        grad = grads.copy() if batched else grads[0].copy()
+        return loss, grad
+
+    def loss(self, params: ndarray) -> float:
+        llhd, _ = self._evaluate(params, False)
+        self.loss_value = llhd
+        return llhd
+
+    def grad(self, params: ndarray) -> ndarray:
+        _, jac = self._evaluate(params, True)
+        self.grad_value = jac
+        return jac
+
+    def loss_and_grad(self, params: ndarray) -> Tuple[float, ndarray]:
+        llhd, jac = self._evaluate(params, True)
+        self.loss_value = llhd
+        self.grad_value = jac
+        return (llhd, jac)

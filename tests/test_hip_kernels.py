@@ -300,11 +300,11 @@ def test_predict_mean_q(ops):
     ops.kernel_build(spec, hpd, xd, xpd, ks)
     mean, q = ops.empty(mpad), ops.empty(mpad)
     work = ops.empty((npad // 64) * mpad)
-    ops.predict_mean_q(ks, minv, alpha, mean, q, work)
-    mu_ref, var_ref = orc.gp_predict(covs, hp, x, y, xp, "diag", form="direct")
     kss = hp[0] ** 2 + hp[-1] ** 2
+    ops.predict_mean_q(ks, minv, alpha, mean, q, kss, work)
+    mu_ref, var_ref = orc.gp_predict(covs, hp, x, y, xp, "diag", form="direct")
     np.testing.assert_allclose(host(mean)[:m], mu_ref, atol=1e-10)
-    np.testing.assert_allclose(kss - host(q)[:m], var_ref, atol=1e-11)
+    np.testing.assert_allclose(host(q)[:m], var_ref, atol=1e-11)
     # full covariance pieces: V = Minv Ks, C = Kss - V^T V
     v = ops.empty(npad, mpad)
     ops.trmm_lower(minv, ks, v)
@@ -320,7 +320,10 @@ def test_grbcm_terms(ops):
     m = 300
     mc, vc, vg, mg = rng.standard_normal(m), 0.1 + rng.random(m), 0.2 + rng.random(m), rng.standard_normal(m)
     out = ops.zeros(3, m)
-    ops.grbcm_local_terms(dev(mc), dev(vc), dev(vg), True, False, out)
+    beta, prec = ops.empty(m), ops.empty(m)
+    ops.grbcm_local_terms(dev(mc), dev(vc), dev(vg), True, False, out, beta, prec)
+    np.testing.assert_allclose(host(beta), 1.0)
+    np.testing.assert_allclose(host(prec), 1.0 / vc, rtol=1e-14)
     ops.grbcm_local_terms(dev(mc * 0.5), dev(vc * 1.3), dev(vg), False, True, out)
     ref = orc.grbcm_terms(mc, vc, vg, True) + orc.grbcm_terms(mc * 0.5, vc * 1.3, vg, False)
     np.testing.assert_allclose(host(out), ref, rtol=1e-13)

@@ -1,0 +1,355 @@
+"""GPU parity of the PyGPR-compatible class surface: golden vectors captured from the reference
+(tests/golden/*.npz), the CPU oracle on seeded inputs, and the reference's own property tests restated
+(PyGPR/tests/test_covar.py, test_gpr.py, test_loss.py, test_grbcm.py) with fixed seeds.
+
+Stated fp64 tolerances: with sigma_n = 0.1 NLML rtol 1e-10, gradient rtol 1e-8 on |g|_inf,
+mean atol 1e-10, variance atol 1e-11; default hp (sigma_n = 1e-4, cond(K) ~ 1e9): NLML 1e-8, grad 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pygpr_amd as pg
+from oracle import pygpr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+COV = {"se": pg.Squared_exponential, "wn": pg.White_noise}
+OCOV = {"se": orc.SE, "wn": orc.WN}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_cov(spec):
+    names = str(spec).split(",")
+    return COV[names[0]]() if len(names) == 1 else pg.Compose([COV[s]() for s in names])
+
+
+def se_wn():
+    return pg.Compose([pg.Squared_exponential(), pg.White_noise()])
+
+
+@pytest.fixture(autouse=True)
+def _scratch_cwd(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)  # optimisers write opt.dat into cwd (opt.py:48)
+
+
+# ------------------------------------------------------------------ covariance kernels
+def test_covar_golden(golden):
+    g = golden("covar")
+    for i in range(int(g["ncase"])):
+        p = "c%02d_" % i
+        cov = make_cov(g[p + "spec"])
+        x, xp, hp = T(g[p + "x"]), T(g[p + "xp"]), T(g[p + "hp"])
+        k = cov.kernel(hp, x)
+        assert k.shape == g[p + "k"].shape and k.dtype == torch.float64 and k.device.type == "cpu"
+        np.testing.assert_allclose(N(k), g[p + "k"], atol=1e-13)
+        k2, dk = cov.kernel_and_grad(hp, x)
+        np.testing.assert_allclose(N(k2), g[p + "k"], atol=1e-13)
+        assert dk.shape == g[p + "dk"].shape
+        np.testing.assert_allclose(N(dk), g[p + "dk"], atol=1e-12)
+        ks = cov.kernel(hp, x, xp)
+        if g[p + "ks"].ndim == 0:
+            assert ks.dim() == 0 and int(ks) == 0 and ks.dtype == torch.int64   # covar.py:243
+        else:
+            assert ks.shape == g[p + "ks"].shape
+            np.testing.assert_allclose(N(ks), g[p + "ks"], atol=1e-13)
+        assert torch.equal(hp, T(g[p + "hp"])) and torch.equal(x, T(g[p + "x"]))   # callers' tensors untouched
+
+
+def test_covar_protocol_shapes_and_errors():
+    x = torch.rand(4, 10, 3, dtype=torch.float64)
+    cov = pg.Compose([pg.Squared_exponential(), pg.Squared_exponential(), pg.White_noise()])
+    assert cov.get_params_shape(x) == [4, 9]
+    hp = cov.init_params(x)
+    assert hp.shape == (4, 9) and float(hp[0, -1]) == 1e-4 and float(hp[0, 0]) == 1.0
+    with pytest.raises(AssertionError):
+        cov.kernel(torch.ones(4, 8, dtype=torch.float64), x)
+    # hp [nc, .] against unbatched x broadcasts to [nc, n, n]
+    k = pg.Squared_exponential().kernel(torch.rand(3, 4, dtype=torch.float64) + 0.5, x[0])
+    assert k.shape == (3, 10, 10)
+
+
+@pytest.mark.parametrize("n,d", [(10, 2), (100, 5), (1000, 2)])
+def test_covar_properties(n, d):
+    """test_covar.py:90-163 restated: symmetric, PD with jitter, analytic dK vs forward FD."""
+    torch.manual_seed(n + d)
+    cov = pg.Compose([pg.Squared_exponential(), pg.Squared_exponential(), pg.White_noise()])
+    x = torch.rand(n, d, dtype=torch.float64)
+    hp = torch.rand(2 * d + 3, dtype=torch.float64)
+    k, dk = cov.kernel_and_grad(hp, x)
+    assert torch.equal(k, k.T)
+    assert torch.linalg.eigvalsh(k + 1e-7 * torch.eye(n, dtype=torch.float64)).min() > 0
+    eps = 1e-5
+    for p in range(hp.numel()):
+        hp2 = hp.clone()
+        hp2[p] += eps
+        fd = (cov.kernel(hp2, x) - k) / eps
+        assert torch.allclose(dk[p], fd, atol=1e-4)
+
+
+def test_matern52_against_oracle():
+    rng = np.random.default_rng(3)
+    x, xp = rng.random((70, 4)), rng.random((9, 4))
+    hp = np.array([1.3, 0.7, 1.1, 0.9, 1.4])
+    cov = pg.Matern52()
+    np.testing.assert_allclose(N(cov.kernel(T(hp), T(x))), orc.matern52_kernel(hp, x), atol=1e-13)
+    np.testing.assert_allclose(N(cov.kernel(T(hp), T(x), T(xp))), orc.matern52_kernel(hp, x, xp), atol=1e-13)
+    k, dk = cov.kernel_and_grad(T(hp), T(x))
+    np.testing.assert_allclose(N(dk), orc.matern52_kernel_and_grad(hp, x)[1], atol=1e-12)
+
+
+# ------------------------------------------------------------------ Exact_GP
+def test_exact_gp_golden(golden):
+    g = golden("gp")
+    gp = pg.Exact_GP(T(g["a_x"]), T(g["a_y"]), se_wn())
+    assert gp.need_upd and torch.equal(gp.params, T(g["a_hp0"]))
+    gp.set_params(T(g["a_hp"]))
+    mu, var = gp.predict(T(g["a_xp"]), var="diag")
+    assert not gp.need_upd
+    np.testing.assert_allclose(N(mu), g["a_mu"], atol=1e-10)
+    np.testing.assert_allclose(N(var), g["a_var"], atol=1e-11)
+    mu, cov = gp.predict(T(g["a_xp"]), var="full")
+    np.testing.assert_allclose(N(cov), g["a_cov"], atol=1e-11)
+    assert torch.equal(cov, cov.T)
+    np.testing.assert_allclose(N(gp.krn), g["a_krn"], atol=1e-13)
+    np.testing.assert_allclose(N(gp.krnchd), g["a_chol"], atol=1e-11)
+    np.testing.assert_allclose(N(gp.wt), g["a_wt"], rtol=1e-8)
+    mu, none = gp.predict(T(g["a_xp"]), var="none")
+    assert none is NotImplemented
+    # SK_WRAP: fit + predict + score (scikit_model.py:15-35)
+    sk = pg.SK_WRAP(gp).fit(T(g["a_x"]), T(g["a_y"]))
+    np.testing.assert_allclose(N(sk.predict(T(g["a_xp"]))), g["a_sk_mu"], atol=1e-10)
+    np.testing.assert_allclose(sk.score(T(g["a_x"]), T(g["a_y"])), g["a_sk_score"], rtol=1e-8)
+
+
+def test_exact_gp_cfg1_and_batched(golden):
+    g = golden("gp")
+    gp = pg.Exact_GP(T(g["b_x"]), T(g["b_y"]), se_wn())
+    gp.set_params(T(g["b_hp"]))
+    mu, var = gp.predict(T(g["b_xp"]), var="diag")
+    np.testing.assert_allclose(N(mu), g["b_mu"], atol=1e-10)
+    np.testing.assert_allclose(N(var), g["b_var"], atol=1e-11)
+    # batched experts
+    gp = pg.Exact_GP(T(g["c_x"]), T(g["c_y"]), se_wn())
+    gp.set_params(T(g["c_hp"]))
+    mu, var = gp.predict(T(g["c_xp"]), var="diag")
+    assert mu.shape == g["c_mu"].shape and var.shape == g["c_var"].shape
+    np.testing.assert_allclose(N(mu), g["c_mu"], atol=1e-10)
+    np.testing.assert_allclose(N(var), g["c_var"], atol=1e-11)
+    _, cov = gp.predict(T(g["c_xp"]), var="full")
+    np.testing.assert_allclose(N(cov), g["c_cov"], atol=1e-11)
+    np.testing.assert_allclose(N(gp.krnchd), g["c_chol"], atol=1e-11)
+    np.testing.assert_allclose(N(gp.wt), g["c_wt"], rtol=1e-8)
+    # squeeze_() semantics for a single test point (SURVEY a-9 / a-10)
+    mu1, var1 = gp.predict(T(g["c_xp"][:1]), var="diag")
+    assert mu1.shape == (4,) and var1.shape == (4, 1)
+
+
+@pytest.mark.parametrize("n,nc", [(100, None), (50, 5)])
+def test_exact_gp_properties(n, nc):
+    """test_gpr.py:17-100 restated: interpolation of y = sin(-sum x), covariance symmetric PSD."""
+    torch.manual_seed(n)
+    d = 3
+    x = torch.rand((n, d) if nc is None else (nc, n, d), dtype=torch.float64)
+    y = torch.sin(-x.sum(-1))
+    gp = pg.Exact_GP(x, y, se_wn())
+    xs = x if nc is None else x[0]
+    mu, cov = gp.predict(xs, var="full")
+    target = y if nc is None else y[0]
+    assert torch.allclose(mu if nc is None else mu[0], target, atol=1e-4)
+    c0 = cov if nc is None else cov[0]
+    assert torch.allclose(c0, c0.T, atol=1e-7)
+    assert torch.linalg.eigvalsh(c0).min() > -1e-7
+    if nc is not None:
+        assert mu.shape == (nc, n) and cov.shape == (nc, n, n)
+
+
+def test_not_positive_definite_raises():
+    """torch.cholesky raises torch.linalg.LinAlgError (a RuntimeError) naming the failing leading minor
+    (SURVEY 5 / 8b); a NaN hyper-parameter makes the very first pivot fail."""
+    x = torch.rand(40, 2, dtype=torch.float64)
+    gp = pg.Exact_GP(x, torch.rand(40, dtype=torch.float64), se_wn())
+    gp.set_params(torch.tensor([float("nan"), 1.0, 1.0, 0.1], dtype=torch.float64))
+    with pytest.raises(torch.linalg.LinAlgError, match="leading minor of order 1 "):
+        gp.update()
+    with pytest.raises(RuntimeError):
+        pg.MLE(gp).loss_and_grad(np.array([float("nan"), 1.0, 1.0, 0.1]))
+    gp.set_params(torch.tensor([1.0, 1.0, 1.0, 0.1], dtype=torch.float64))
+    gp.update()                                   # the model recovers with valid parameters
+
+
+# ------------------------------------------------------------------ MLE
+def test_mle_golden(golden):
+    g = golden("gp")
+    gp = pg.Exact_GP(T(g["a_x"]), T(g["a_y"]), se_wn())
+    mle = pg.MLE(gp)
+    loss = mle.loss(g["a_hp"].copy())
+    assert isinstance(loss, np.ndarray) and loss.ndim == 0
+    np.testing.assert_allclose(loss, g["a_loss"], rtol=1e-10)
+    grad = mle.grad(g["a_hp"].copy())
+    np.testing.assert_allclose(grad, g["a_grad"], rtol=1e-8, atol=1e-8 * np.abs(g["a_grad"]).max())
+    l2, g2 = mle.loss_and_grad(g["a_hp"].copy())
+    np.testing.assert_allclose(l2, g["a_loss2"], rtol=1e-10)
+    np.testing.assert_allclose(g2, g["a_grad2"], rtol=1e-8, atol=1e-8 * np.abs(g["a_grad2"]).max())
+    assert mle.loss_value is l2 and mle.grad_value is g2
+    l0, g0 = mle.loss_and_grad(g["a_hp0"].copy())                      # cond(K) ~ 1e9
+    np.testing.assert_allclose(l0, g["a_loss0"], rtol=1e-8)
+    np.testing.assert_allclose(g0, g["a_grad0"], rtol=1e-5, atol=1e-5 * np.abs(g["a_grad0"]).max())
+    # cfg1 known answer
+    gpb = pg.Exact_GP(T(g["b_x"]), T(g["b_y"]), se_wn())
+    lb, gb = pg.MLE(gpb).loss_and_grad(g["b_hp"].copy())
+    np.testing.assert_allclose(lb, g["b_loss"], rtol=1e-10)
+    np.testing.assert_allclose(gb, g["b_grad"], rtol=1e-8, atol=1e-8 * np.abs(g["b_grad"]).max())
+    lb0, gb0 = pg.MLE(gpb).loss_and_grad(g["b_hp0"].copy())
+    np.testing.assert_allclose(lb0, -3461.42170686, rtol=1e-8)
+    np.testing.assert_allclose(gb0, g["b_grad0"], rtol=1e-5)
+    # batched [nc, nhp]
+    gpc = pg.Exact_GP(T(g["c_x"]), T(g["c_y"]), se_wn())
+    lc, gc = pg.MLE(gpc).loss_and_grad(g["c_hp"].copy())
+    assert lc.shape == g["c_loss"].shape and gc.shape == g["c_grad"].shape
+    np.testing.assert_allclose(lc, g["c_loss"], rtol=1e-10)
+    np.testing.assert_allclose(gc, g["c_grad"], rtol=1e-8, atol=1e-8 * np.abs(g["c_grad"]).max())
+    np.testing.assert_allclose(pg.MLE(gpc).loss(g["c_hp"].copy()), g["c_lossonly"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("n,d", [(10, 2), (100, 3), (1000, 5), (100, 7)])
+def test_mle_grad_vs_fd(n, d):
+    """test_loss.py:17-44 restated (forward FD of MLE.loss); central differences, looser eps."""
+    torch.manual_seed(n * d)
+    x = torch.rand(n, d, dtype=torch.float64)
+    y = torch.sin(-x.sum(-1))
+    mle = pg.MLE(pg.Exact_GP(x, y, se_wn()))
+    hp = np.random.default_rng(n).random(d + 2) * 0.5 + 0.5
+    hp[-1] = 0.05 + 0.05 * hp[-1]
+    grad = mle.grad(hp.copy())
+    fd = np.empty_like(hp)
+    for p in range(hp.size):
+        e = np.zeros_like(hp)
+        e[p] = 1e-6
+        fd[p] = (mle.loss(hp + e) - mle.loss(hp - e)) / 2e-6
+    assert np.max(np.abs(fd - grad)) < 1e-3 * max(1.0, np.abs(grad).max())
+
+
+def test_learn_rate_and_cg(golden):
+    g = golden("gp")
+    gp = pg.Exact_GP(T(g["a_x"]), T(g["a_y"]), se_wn())
+    gam = pg.get_learn_rate(T(g["a_hp"]), pg.MLE(gp), 1e-6)
+    np.testing.assert_allclose(gam, g["a_gamma"], rtol=5e-2)     # eps = 1e-6 second difference: noisy by nature
+    gpd = pg.Exact_GP(T(g["d_x"]), T(g["d_y"]), se_wn())
+    gpd.set_params(T(g["d_hp"]))
+    cg = pg.CG(pg.MLE(gpd))
+    cg.args["maxiter"] = 5
+    cg.args["disp"] = False
+    cg.minimize()
+    assert os.path.exists("opt.dat")
+    assert int(cg.res.nit) == int(g["d_nit"])
+    np.testing.assert_allclose(cg.res.fun, g["d_res_fun"], rtol=1e-6)
+    np.testing.assert_allclose(cg.res.x, g["d_res_x"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(gpd.params), g["d_params"], rtol=1e-4, atol=1e-5)
+    assert gpd.need_upd
+
+
+def test_quadratic_optimisers_on_a_mock_loss():
+    """test_opt.py:20-56 restated: CG_Quad / BFGS_Quad reach solve(H, -J) on a random SPD quadratic."""
+    rng = np.random.default_rng(5)
+    dim = 6
+    a = rng.standard_normal((dim, dim))
+    h = a @ a.T + dim * np.eye(dim)
+    j = rng.standard_normal(dim)
+    for cls in (pg.CG_Quad, pg.BFGS_Quad):
+        loss = pg.Loss(None)
+        loss.loss = lambda x: 0.5 * x @ h @ x + j @ x
+        loss.grad = lambda x: h @ x + j
+        opt = cls(loss, gtol=1e-8, max_iter=200)
+        opt.minimize(par=np.zeros(dim))
+        assert np.all(np.isclose(opt.x, np.linalg.solve(h, -j), rtol=1e-3))
+    np.testing.assert_allclose(pg.hessian(np.zeros(dim), lambda x: h @ x + j, 1e-6), h, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ grBCM
+def test_grbcm_golden(golden):
+    g = golden("grbcm")
+    for i in range(int(g["ncase"])):
+        p = "g%d_" % i
+        m = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), se_wn())
+        m.gpg.set_params(T(g[p + "hpg"]))
+        m.gpl.set_params(T(g[p + "hpl"]))
+        mu, var = m.predict(T(g[p + "xs"]), var="diag")
+        np.testing.assert_allclose(N(mu), g[p + "mu"], atol=1e-10)
+        np.testing.assert_allclose(N(var), g[p + "var"], atol=1e-11)
+        np.testing.assert_allclose(N(m.beta), g[p + "beta"], atol=1e-9)
+        np.testing.assert_allclose(N(m.prec), g[p + "prec"], rtol=1e-9)
+        assert (m.nc, m.nsc, m.ng, m.dim) == (g[p + "xl"].shape[0], 50, 20, 3)
+
+
+@pytest.mark.parametrize("ng,nc,n,d", [(10, 2, 10, 2), (100, 5, 50, 3), (100, 10, 100, 7)])
+def test_grbcm_reproduces_targets(ng, nc, n, d):
+    """test_grbcm.py:18-37 restated: predicting one local shard reproduces sin(sum x)."""
+    torch.manual_seed(ng + nc + n + d)
+    xg = torch.rand(ng, d, dtype=torch.float64)
+    xl = torch.rand(nc, n, d, dtype=torch.float64)
+    m = pg.GRBCM(xl, torch.sin(xl.sum(-1)), xg, torch.sin(xg.sum(-1)), se_wn())
+    mu, var = m.predict(xl[0], var="diag")
+    assert torch.allclose(mu, torch.sin(xl[0].sum(-1)), atol=1e-4)
+
+
+def test_grbcm_shared_hp_objective_matches_summed_oracle(golden):
+    g = golden("grbcm")
+    p = "g1_"
+    m = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), se_wn())
+    hp = g[p + "hpg"].copy()
+    loss, grad = pg.GRBCM_MLE(m).loss_and_grad(hp)
+    x, y = orc.grbcm_data(g[p + "xl"], g[p + "yl"], g[p + "xg"], g[p + "yg"])
+    ref = [orc.mle_loss_and_grad([orc.SE, orc.WN], hp, x[c], y[c], "kinv") for c in range(x.shape[0])]
+    np.testing.assert_allclose(loss, sum(r[0] for r in ref), rtol=1e-10)
+    gref = sum(r[1] for r in ref)
+    np.testing.assert_allclose(grad, gref, rtol=1e-8, atol=1e-8 * np.abs(gref).max())
+
+
+# ------------------------------------------------------------------ fp32 opt-in and full-size properties
+def test_fp32_opt_in():
+    n, d = 600, 8
+    x, y = orc.synth(n, d, seed=2)
+    xp = np.random.default_rng(1).random((40, d))
+    hp = np.concatenate([[1.0], np.full(d, 0.7), [0.1]])
+    cov = pg.Compose([pg.Matern52(), pg.White_noise()])
+    gp = pg.Exact_GP(T(x).float(), T(y).float(), cov)
+    gp.set_params(T(hp))
+    mu, var = gp.predict(T(xp).float(), var="diag")
+    assert mu.dtype == torch.float32
+    mu_ref, var_ref = orc.gp_predict([orc.M52, orc.WN], hp, x, y, xp, "diag")
+    np.testing.assert_allclose(N(mu), mu_ref, atol=2e-3)
+    np.testing.assert_allclose(N(var), var_ref, atol=2e-3)
+    loss, grad = pg.MLE(gp).loss_and_grad(hp.copy())
+    l_ref, g_ref = orc.mle_loss_and_grad([orc.M52, orc.WN], hp, x, y, "kinv")
+    np.testing.assert_allclose(loss, l_ref, rtol=1e-3)
+    np.testing.assert_allclose(grad, g_ref, rtol=2e-2, atol=2e-2 * np.abs(g_ref).max())
+
+
+def test_cfg2_size_properties():
+    """BASELINE config 2 (N=8192, D=8, fp64): size-independent properties instead of an O(n^3) oracle run --
+    (i) the gradient agrees with central differences of the loss along a random direction,
+    (ii) predicting the training inputs gives K alpha' = y - (sigma_n^2 + jitter) alpha, i.e. the factor solves K."""
+    n, d = 8192, 8
+    x, y = orc.synth(n, d, seed=1234)
+    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
+    gp = pg.Exact_GP(T(x), T(y), se_wn())
+    mle = pg.MLE(gp)
+    loss, grad = mle.loss_and_grad(hp.copy())
+    v = np.random.default_rng(0).standard_normal(hp.size)
+    v /= np.linalg.norm(v)
+    eps = 1e-5
+    fd = (mle.loss(hp + eps * v) - mle.loss(hp - eps * v)) / (2 * eps)
+    np.testing.assert_allclose(grad @ v, fd, rtol=1e-5)
+    gp.set_params(T(hp))
+    mu, _ = gp.predict(T(x[:2048]), var="none")
+    alpha = N(gp.wt)
+    np.testing.assert_allclose(N(mu), y[:2048] - (hp[-1] ** 2 + 1e-7) * alpha[:2048], atol=1e-8)
