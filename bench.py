@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): NLML+gradient evaluations/sec at N=16384, D=8, RBF + white noise, fp64.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = every rank evaluates `loss_and_grad` (PyGPR/loss.py:92-128) once for ITS expert -- covariance
+build, Cholesky, L^-1, alpha, K^-1, fused gradient contraction at n = 16384, d = 8 -- followed, for N > 1, by
+the shared-hyper-parameter all-reduce(sum) of [1 + nhp] doubles over RCCL (grBCM co-training, GRBCM_MLE).
+At N = 1 that is exactly one exact-GP NLML+grad evaluation.  value = N * K / t (weak scaling, whole job).
+
+Extra objects on the same JSON line:
+  roofline      the MFMA GEMM core (all instantiations of pg_gemm_kernel) over one evaluation: algorithmic
+                flop of its launches / summed launch durations measured with HIP events inside the library
+                (pg_profile), against the fp64 matrix peak; plus potrf alone and the covariance build (HBM)
+  cpu_baseline  the CPU oracle's lean K^-1-route evaluation (oracle/pygpr_oracle.py, LAPACK via SciPy) timed
+                on this host's cores at a bounded size and n^3-scaled to N = 16384
+  grbcm_predict BASELINE config 4 (8 experts x (1024 + 8192) points, D = 16, 65536 test points): committee
+                predictions/sec, experts sharded over the ranks, one [3, m] all-reduce per test batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk / SIMD, 2.4 GHz)
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def synth_expert(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    y = np.sin(-x.sum(1)) + 0.1 * rng.standard_normal(n)
+    return x, y
+
+
+def cpu_baseline(n_full, d, n_cpu):
+    """Oracle (kind = "port"), lean K^-1 route, all host cores, n^3-scaled to n_full."""
+    from oracle import pygpr_oracle as orc
+
+    x, y = synth_expert(n_cpu, d, 1234)
+    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
+    orc.mle_loss_and_grad_lean(hp, x[:512], y[:512])          # warm LAPACK threads
+    t0 = time.perf_counter()
+    orc.mle_loss_and_grad_lean(hp, x, y)
+    t = time.perf_counter() - t0
+    scale = (n_full / n_cpu) ** 3
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {
+        "value": 1.0 / (t * scale), "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": "1 lean K^-1-route NLML+grad eval (oracle.mle_loss_and_grad_lean: SciPy dpotrf + dpotri, fp64, "
+                  "BLAS threads = host cores) at N=%d D=%d took %.2f s; n^3-scaled x%.0f to N=%d" % (n_cpu, d, t, scale, n_full),
+        "seconds_measured": t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=16384, help="points per expert (BASELINE: 16384)")
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--ng", type=int, default=1024, help="size of the grBCM global/communication set")
+    ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grbcm", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pygpr_amd as pg
+    from pygpr_amd._ops import get_ops, make_spec
+
+    ops = get_ops()
+    n, d, ng = args.n, args.d, args.ng
+    nls = n - ng
+    cov = pg.Compose([pg.Squared_exponential(), pg.White_noise()])
+    hp = np.concatenate([[1.0], np.ones(d), [0.1]])            # sigma, l_1..l_d, sigma_n
+
+    # one expert per rank, n = ng + nls points: global set (shared) + own shard
+    xg, yg = synth_expert(ng, d, 99)
+    shards = [synth_expert(nls, d, 1234 + r) for r in range(world)]
+    xl = torch.from_numpy(np.stack([s[0] for s in shards]))
+    yl = torch.from_numpy(np.stack([s[1] for s in shards]))
+    model = pg.GRBCM(xl, yl, torch.from_numpy(xg), torch.from_numpy(yg), cov, distributed=(world > 1))
+    loss = pg.GRBCM_MLE(model)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss.loss_and_grad(hp)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        val, grad = loss.loss_and_grad(hp)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "NLML+grad evals/sec at N=%d D=%d RBF" % (n, d), "value": value, "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 3: one exact-GP NLML+gradient evaluation per GPU per step, N=%d D=%d, "
+                        "Compose([Squared_exponential, White_noise]), hp sigma=1 l=1 sigma_n=0.1, jitter 1e-7; "
+                        "N>1: grBCM shared-hp co-training (each rank's expert = %d global + %d own points), one "
+                        "all-reduce of [1+nhp] per step" % (n, d, ng, nls),
+            "experts_per_gpu": 1, "nlml": float(val), "grad_inf": float(np.abs(grad).max()),
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: one profiled evaluation (events around every GEMM launch)
+        ops.profile(1)
+        loss.loss_and_grad(hp)
+        torch.cuda.synchronize()
+        ops.profile(0)
+        flops, ms, launches = ops.profile_read()
+        achieved = flops / ms / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "kernel": "pg_gemm_kernel<double,...> (MFMA GEMM core, all instantiations) over one evaluation",
+            "launches": launches, "avg_launch_ms": ms / max(launches, 1), "flops_per_launch": flops / max(launches, 1),
+            "algorithmic_flops_per_eval": float(n) ** 3, "eval_tflops": float(n) ** 3 / (elapsed / args.steps) / 1e12,
+        }
+        # potrf alone and the covariance build, HIP events on torch's current stream (the library's stream)
+        exp = model.gpl._device_experts()[0]
+        npad = exp.n_pad
+        spec = make_spec([0], [0], [d + 1])
+        hpd = torch.from_numpy(hp).cuda()
+        a = ops.empty(npad, npad)
+        invd = ops.potrf_workspace(npad, torch.float64)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            return best
+
+        t_build = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, jitter=1e-7), 5)
+        bytes_build = 8.0 * n * n + 8.0 * n * d
+        out["roofline_kernel_build"] = {
+            "bound": "hbm", "achieved": bytes_build / t_build / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_build / t_build / 1e6 / HBM_PEAK_GBS, "ms": t_build, "algorithmic_bytes": bytes_build,
+        }
+        t_lower = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)
+
+        def fac():
+            ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7)
+            ops.potrf(a, invd, info)
+
+        t_potrf = timed(fac, 3) - t_lower
+        out["cholesky"] = {"ms": t_potrf, "tflops": n ** 3 / 3.0 / t_potrf / 1e9,
+                           "frac_of_fp64_matrix_peak": n ** 3 / 3.0 / t_potrf / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
+        del a, invd
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, min(args.cpu_n, n))
+            out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
+
+    # ---- secondary metric: grBCM committee prediction throughput (BASELINE config 4)
+    if not args.no_grbcm:
+        del model, loss
+        torch.cuda.empty_cache()
+        nc, nls4, ng4, d4, m4, mb = 8, 8192, 1024, 16, 65536, 8192
+        xg4, yg4 = synth_expert(ng4, d4, 7)
+        sh = [synth_expert(nls4, d4, 100 + c) for c in range(nc)]
+        g4 = pg.GRBCM(torch.from_numpy(np.stack([s[0] for s in sh])), torch.from_numpy(np.stack([s[1] for s in sh])),
+                      torch.from_numpy(xg4), torch.from_numpy(yg4), cov, distributed=(world > 1))
+        hp4 = torch.from_numpy(np.concatenate([[1.0], np.full(d4, 0.5), [0.1]]))
+        g4.gpg.set_params(hp4)
+        g4.set_local_params(hp4)
+        xs = torch.from_numpy(np.random.default_rng(4321).random((m4, d4))).cuda()
+        g4.predict(xs[:mb])                                     # fit (factorise, invert) + warm-up batch
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(0, m4, mb):
+            mu, var = g4.predict(xs[s: s + mb])
+        barrier()
+        tp = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([tp], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tp = float(tt.item())
+        out["grbcm_predict"] = {
+            "value": m4 / tp, "unit": "points/s", "scaling": "strong", "seconds": tp,
+            "config": "8 experts x (%d global + %d local) points, D=%d, RBF+noise fp64, %d test points in batches of %d, "
+                      "diag variance; experts sharded over %d rank(s); one [3,m] all-reduce per batch" % (ng4, nls4, d4, m4, mb, world),
+            "mean_abs": float(mu.abs().mean()), "var_mean": float(var.mean()),
+        }
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

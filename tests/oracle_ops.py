@@ -1,0 +1,171 @@
+"""TEST DOUBLE of pygpr_amd._ops.HipOps for the CPU test tier: the same method surface on CPU tensors,
+every number produced by NumPy/SciPy (the oracle's arithmetic).  It exists so that the HOST logic --
+shapes, broadcasting, padding, error conventions, optimiser drivers, the multi-rank reductions -- can
+be exercised where there is no GPU.  It lives under tests/ and is never imported by the product; tests
+install it by monkeypatching `pygpr_amd._ops._OPS`."""
+import numpy as np
+import scipy.linalg as sla
+import torch
+
+from oracle import pygpr_oracle as orc
+
+NB = 256
+
+
+def _np(t):
+    return t.detach().numpy()
+
+
+def _covs(spec, hp, d):
+    """(kind, hp slice) list from a pg_covspec."""
+    comps = [("se" if spec.kind[c] == 0 else "matern52", hp[spec.off[c]: spec.off[c] + d + 1]) for c in range(spec.ncomp)]
+    noise = [hp[spec.noise_off[i]] for i in range(spec.nnoise)]
+    return comps, noise
+
+
+def _k(comps, xr, xc):
+    out = np.zeros((xr.shape[0], xc.shape[0]))
+    for kind, h in comps:
+        if kind == "se":
+            out += orc.se_kernel(h, xc, xr, form="direct")
+        else:
+            out += orc.matern52_kernel(h, xc, xr)
+    return out
+
+
+class OracleOps:
+    device = torch.device("cpu")
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.full(tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape,
+                          float("nan"), dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def to_device(self, t, dtype=None):
+        return t.detach().to(dtype=dtype if dtype is not None else t.dtype).contiguous().clone()
+
+    # covariance
+    def kernel_build(self, spec, hp, xr, xc, out, lower_only=False, jitter=0.0):
+        h, x = _np(hp), _np(xr).astype(np.float64)
+        comps, noise = _covs(spec, h, x.shape[1])
+        o = _np(out)
+        if xc is None:
+            n = x.shape[0]
+            full = np.eye(o.shape[0])
+            full[:n, :n] = _k(comps, x, x) + (sum(s * s for s in noise) + jitter) * np.eye(n)
+            if lower_only:
+                mask = np.tril(np.ones_like(full, dtype=bool))
+                o[mask] = full[mask]
+            else:
+                o[...] = full
+        else:
+            xq = _np(xc).astype(np.float64)
+            o[...] = 0.0
+            o[: x.shape[0], : xq.shape[0]] = _k(comps, x, xq)
+        return out
+
+    def kernel_grad_build(self, spec, hp, x, out):
+        h, xx = _np(hp), _np(x).astype(np.float64)
+        d = xx.shape[1]
+        o = _np(out)
+        o[...] = 0.0
+        for c in range(spec.ncomp):
+            sl = slice(spec.off[c], spec.off[c] + d + 1)
+            fn = orc.se_kernel_and_grad if spec.kind[c] == 0 else orc.matern52_kernel_and_grad
+            o[sl] = fn(h[sl], xx, **({"form": "direct"} if spec.kind[c] == 0 else {}))[1]
+        for i in range(spec.nnoise):
+            o[spec.noise_off[i]] = 2.0 * h[spec.noise_off[i]] * np.eye(xx.shape[0])
+        return out
+
+    # factorisation
+    def potrf_workspace(self, n_pad, dtype):
+        return torch.zeros(n_pad * NB + 128 * 128, dtype=dtype)
+
+    def potrf(self, a, invd, info):
+        m = np.tril(_np(a).astype(np.float64))
+        m = m + np.tril(m, -1).T
+        c, inf = sla.lapack.dpotrf(m, lower=1)
+        if not np.isfinite(m).all():
+            inf = inf or 1
+        info[0] = int(inf)
+        if inf == 0:
+            low = np.tril(c)
+            idx = np.tril_indices(m.shape[0])
+            _np(a)[idx] = low[idx]
+
+    def potrs_vec(self, chol, invd, y, x):
+        x.copy_(torch.from_numpy(sla.cho_solve((np.tril(_np(chol).astype(np.float64)), True), _np(y).astype(np.float64),
+                                              check_finite=False)))
+
+    def trtri(self, chol, invd, minv):
+        low = np.tril(_np(chol).astype(np.float64))
+        minv.copy_(torch.from_numpy(sla.solve_triangular(low, np.eye(low.shape[0]), lower=True, check_finite=False)))
+
+    def lauum(self, minv, kinv):
+        m = np.tril(_np(minv).astype(np.float64))
+        kinv.copy_(torch.from_numpy(np.tril(m.T @ m)))
+
+    def trmv(self, minv, x, y, trans, work=None):
+        m = np.tril(_np(minv).astype(np.float64))
+        y.copy_(torch.from_numpy((m.T if trans else m) @ _np(x).astype(np.float64)))
+
+    def tril(self, a, n):
+        a.copy_(torch.tril(a))
+
+    # NLML
+    def nlml_value(self, chol, y, alpha, n, out):
+        d = np.diag(_np(chol).astype(np.float64))[:n]
+        out[0] = 0.5 * float(_np(y)[:n].astype(np.float64) @ _np(alpha)[:n].astype(np.float64)) \
+            + float(np.log(d).sum()) + 0.5 * n * np.log(2 * np.pi)
+
+    def nlml_grad_worksize(self, n, nhp):
+        return 1
+
+    def nlml_grad(self, spec, hp, x, n, kinv, alpha, grad, work):
+        h, xx = _np(hp), _np(x).astype(np.float64)
+        d = xx.shape[1]
+        ki = np.tril(_np(kinv).astype(np.float64))[:n, :n]
+        ki = ki + np.tril(ki, -1).T
+        al = _np(alpha).astype(np.float64)[:n]
+        w = ki - np.outer(al, al)
+        dk = np.zeros((grad.numel(), n, n))
+        self.kernel_grad_build(spec, hp, x, torch.from_numpy(dk))
+        grad.copy_(torch.from_numpy(0.5 * np.einsum("ij,kij->k", w, dk)))
+
+    # prediction
+    def predict_mean_q(self, ks, minv, alpha, mean, var, kss, work):
+        k = _np(ks).astype(np.float64)
+        mean.copy_(torch.from_numpy(k.T @ _np(alpha).astype(np.float64)))
+        if var is not None:
+            v = np.tril(_np(minv).astype(np.float64)) @ k
+            var.copy_(torch.from_numpy(kss - (v * v).sum(0)))
+
+    def trmm_lower(self, minv, ks, v):
+        v.copy_(torch.from_numpy(np.tril(_np(minv).astype(np.float64)) @ _np(ks).astype(np.float64)))
+
+    def syrk_tn_sub(self, v, c, lower_only=True):
+        vv = _np(v).astype(np.float64)
+        c -= torch.from_numpy(vv.T @ vv)
+
+    # grBCM
+    def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out, beta=None, prec=None):
+        t = orc.grbcm_terms(_np(mean_c).astype(np.float64), _np(var_c).astype(np.float64), _np(var_g).astype(np.float64), is_first)
+        if accumulate:
+            out += torch.from_numpy(t)
+        else:
+            out.copy_(torch.from_numpy(t))
+        if beta is not None:
+            beta.copy_(torch.from_numpy(t[0]))
+        if prec is not None:
+            prec.copy_(torch.from_numpy(1.0 / _np(var_c).astype(np.float64)))
+
+    def grbcm_finish(self, sums, mean_g, var_g, mean, var, beta0=None, prec0=None):
+        mu, v = orc.grbcm_finish(_np(sums), _np(mean_g).astype(np.float64), _np(var_g).astype(np.float64))
+        mean.copy_(torch.from_numpy(mu))
+        var.copy_(torch.from_numpy(v))
+        if beta0 is not None:
+            beta0.copy_(1.0 - sums[0])
+        if prec0 is not None:
+            prec0.copy_(torch.from_numpy(1.0 / _np(var_g).astype(np.float64)))
