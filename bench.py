@@ -52,14 +52,11 @@ def cpu_baseline(n_full, d, n_cpu):
     orc.mle_loss_and_grad_lean(hp, x, y)
     t = time.perf_counter() - t0
     scale = (n_full / n_cpu) ** 3
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
+    cores = torch.get_num_threads()          # intra-op threads the baseline actually used
     return {
         "value": 1.0 / (t * scale), "unit": "evals/s", "cores": cores, "kind": "port",
-        "sample": "1 lean K^-1-route NLML+grad eval (oracle.mle_loss_and_grad_lean: SciPy dpotrf + dpotri, fp64, "
-                  "BLAS threads = host cores) at N=%d D=%d took %.2f s; n^3-scaled x%.0f to N=%d" % (n_cpu, d, t, scale, n_full),
+        "sample": "1 lean K^-1-route NLML+grad eval (oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK potrf + potri, "
+                  "%d intra-op threads) at N=%d D=%d took %.2f s; n^3-scaled x%.0f to N=%d" % (cores, n_cpu, d, t, scale, n_full),
         "seconds_measured": t,
     }
 

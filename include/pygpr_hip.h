@@ -64,14 +64,14 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
                          int n, int d, void* dK, void* stream);
 
 /* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag receives the
- * inverses of the 256x256 diagonal blocks ([n/256][256][256]); they drive every later solve. */
+ * inverses of the 128x128 diagonal blocks ([n/128][128][128]); they drive every later solve. */
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
 
-/* alpha = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is overwritten
- * (work vector), x receives the solution; both length n. */
-int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* y, void* x,
-                 void* stream);
+/* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
+ * work: 2 n elements. */
+int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
+                 void* work, void* stream);
 
 /* Minv = L^-1 (lower; its strictly upper blocks are scratch).  First half of cholesky_solve against a
  * matrix right-hand side (gpr.py:100,112; loss.py:116). */
@@ -125,6 +125,11 @@ int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds,
 
 /* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
+
+/* pg_potrf overlaps its panel chain (auxiliary high-priority stream inside the handle) with the trailing update
+ * on the caller's stream; all work is joined back onto the caller's stream before pg_potrf returns.  on = 0 keeps
+ * everything on the caller's stream (default 1). */
+int pg_set_lookahead(pg_handle h, int on);
 
 /* GEMM-core profiling for bench.py's roofline leg: events around every MFMA GEMM launch */
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */

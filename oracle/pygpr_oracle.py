@@ -271,43 +271,41 @@ def mle_grad(covs, hp, x, y, route="solve", form="gemm"):
     return mle_loss_and_grad(covs, hp, x, y, route, form)[1]
 
 
-def mle_loss_and_grad_lean(hp, x, y, nthreads_note=None):
-    """Lean CPU baseline for bench.py (Compose([SE, WN]) only): the K^-1 route
-    with LAPACK potrf/potri and NO [nhp,n,n] stack -- dK is contracted one
-    hyper-parameter at a time.  Direct-difference distances (same as the HIP
-    kernel).  Memory ~ 4 n^2 doubles."""
+def mle_loss_and_grad_lean(hp, x, y):
+    """Lean CPU baseline for bench.py (Compose([SE, WN]) only): the K^-1 route on the reference's own
+    substrate -- torch CPU fp64, LAPACK potrf/potri through torch.linalg, all intra-op threads -- with NO
+    [nhp,n,n] stack.  The per-dimension contraction sum_ij W_ij K_ij (x_ia - x_ja)^2 is expanded to
+    2 sum_i x_ia^2 r_i - 2 x_a^T (W o K) x_a (r = row sums), i.e. one n x n x d GEMM instead of d n^2 passes.
+    Same numbers as mle_loss_and_grad(route="kinv") to rounding; memory ~ 4 n^2 doubles."""
+    import torch
+
     n, d = x.shape
-    sig, ls, sn = hp[0], hp[1:d + 1], hp[d + 1]
-    xl = x * ls
-    x2 = np.sum(xl * xl, axis=1)
-    kse = -2.0 * (xl @ xl.T)
-    kse += x2[:, None]
-    kse += x2[None, :]
-    np.negative(kse, out=kse)
-    np.exp(kse, out=kse)
-    kse *= sig * sig
-    a = kse.copy()
-    a[np.diag_indices_from(a)] += sn * sn + JITTER
-    chol, info = sla.lapack.dpotrf(a, lower=1, overwrite_a=1)
-    if info != 0:
-        raise np.linalg.LinAlgError("leading minor of order %d not PD" % info)
-    alpha = sla.cho_solve((chol, True), y)
-    loss = 0.5 * float(alpha @ y) + float(np.sum(np.log(np.diag(chol)))) \
-        + 0.5 * n * np.log(2.0 * np.pi)
-    kinv, info = sla.lapack.dpotri(chol, lower=1, overwrite_c=1)
-    # symmetrise (potri fills the lower triangle only)
-    il = np.tril_indices(n, -1)
-    kinv.T[il] = kinv[il]
-    w = kinv
-    w -= np.outer(alpha, alpha)
+    xt, yt = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(y))
+    sig, sn = float(hp[0]), float(hp[d + 1])
+    ls = torch.from_numpy(np.ascontiguousarray(hp[1:d + 1]))
+    xl = xt * ls
+    x2 = (xl * xl).sum(1)
+    kse = torch.addmm(x2[:, None] + x2[None, :], xl, xl.T, alpha=-2.0)      # covar.py:102-127
+    kse.neg_().exp_().mul_(sig * sig)                                          # covar.py:147-149
+    a = kse.clone()
+    a.diagonal().add_(sn * sn + JITTER)
+    chol = torch.linalg.cholesky(a)
+    del a
+    alpha = torch.cholesky_solve(yt[:, None], chol)[:, 0]
+    loss = 0.5 * float(alpha @ yt) + float(torch.log(chol.diagonal()).sum()) + 0.5 * n * np.log(2.0 * np.pi)
+    w = torch.cholesky_inverse(chol)
+    del chol
+    w.addr_(alpha, alpha, alpha=-1.0)                                          # W = K^-1 - a a^T
+    tr_w = float(w.diagonal().sum())
+    w.mul_(kse)                                                                # W o K_se
+    del kse
     g = np.empty(d + 2)
-    wk = w * kse
-    g[0] = 0.5 * (2.0 / sig) * np.sum(wk)
-    for a_ in range(d):
-        diff = x[:, a_][:, None] - x[:, a_][None, :]
-        diff *= diff
-        g[a_ + 1] = 0.5 * (-2.0 * ls[a_]) * np.sum(wk * diff)
-    g[d + 1] = 0.5 * 2.0 * sn * np.trace(w)
+    r = w.sum(1)
+    g[0] = 0.5 * (2.0 / sig) * float(r.sum())
+    wx = w @ xt                                                                # [n, d]
+    quad = 2.0 * ((xt * xt) * r[:, None]).sum(0) - 2.0 * (xt * wx).sum(0)      # sum_ij (W o K)_ij (x_ia - x_ja)^2
+    g[1:d + 1] = (0.5 * -2.0 * ls * quad).numpy()
+    g[d + 1] = 0.5 * 2.0 * sn * tr_w
     return loss, g
 
 

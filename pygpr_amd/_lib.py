@@ -16,7 +16,7 @@ PG_KIND_RBF, PG_KIND_MATERN52 = 0, 1
 PG_MAX_COMP, PG_MAX_DIM = 4, 64
 PAD = 256  # every dimension given to the O(n^3) entry points is a multiple of this
 
-GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT = 0, 1, 2, 3, 5
+GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT, GEMM_NT_64 = 0, 1, 2, 3, 5, 6
 
 
 class CovSpec(C.Structure):
@@ -39,7 +39,7 @@ _SIGS = {
     "pg_kernel_grad_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _vp]),
     "pg_potrf_worksize": (_l, [_i, _i]),
     "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
-    "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
+    "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "pg_trtri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
     "pg_lauum": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _vp]),
     "pg_trmv": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp]),
@@ -52,6 +52,7 @@ _SIGS = {
     "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
+    "pg_set_lookahead": (_i, [_vp, _i]),
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
     "pg_gemm_raw": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _l, _vp, _l, _d, _vp, _l, _i, _i, _i, _vp]),

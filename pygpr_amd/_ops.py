@@ -89,10 +89,12 @@ class HipOps:
         _lib.check(self.lib.pg_potrf(self.h, _code(a.dtype), a.shape[0], _p(a), a.stride(0), _p(invd), _p(info),
                                      self._st()), "pg_potrf")
 
-    def potrs_vec(self, chol, invd, y, x):
-        self._chk(chol, invd, y, x)
+    def potrs_vec(self, chol, invd, y, x, work=None):
+        if work is None:
+            work = self.empty(2 * chol.shape[0], dtype=chol.dtype)
+        self._chk(chol, invd, y, x, work)
         _lib.check(self.lib.pg_potrs_vec(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
-                                         _p(y), _p(x), self._st()), "pg_potrs_vec")
+                                         _p(y), _p(x), _p(work), self._st()), "pg_potrs_vec")
 
     def trtri(self, chol, invd, minv):
         self._chk(chol, invd, minv)
@@ -168,6 +170,9 @@ class HipOps:
         _lib.check(self.lib.pg_gemm_raw(self.h, _code(c.dtype), variant, m, n, k, float(alpha), _p(a), a.stride(0),
                                         _p(b), b.stride(0), float(beta), _p(c), c.stride(0), tri, klo, khi,
                                         self._st()), "pg_gemm_raw")
+
+    def set_lookahead(self, on):
+        _lib.check(self.lib.pg_set_lookahead(self.h, int(on)), "pg_set_lookahead")
 
     def profile(self, on):
         _lib.check(self.lib.pg_profile(self.h, int(on)), "pg_profile")

@@ -4,6 +4,7 @@
 #include "linalg.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[512] = "";
@@ -56,7 +57,27 @@ int pg_create(pg_handle* h) {
     }
     pg_ctx* c = new pg_ctx();
     memset(c, 0, sizeof(*c));
-    PG_CHECK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;
+    PG_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    PG_CHECK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
+    c->lookahead = 1;
+    {   // update stream on all but the last PG_RESERVED_CUS compute units; without it look-ahead stays off
+        hipDeviceProp_t prop;
+        int dev = 0;
+        PG_CHECK(hipGetDevice(&dev));
+        PG_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        const int words = (ncu + 31) / 32;
+        uint32_t mask[64];
+        for (int i = 0; i < 64; ++i) mask[i] = 0;
+        for (int cu = 0; cu < ncu - PG_RESERVED_CUS; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+        if (ncu <= PG_RESERVED_CUS * 4 || words > 64 ||
+            hipExtStreamCreateWithCUMask(&c->upd, (uint32_t)words, mask) != hipSuccess) {
+            c->upd = nullptr;
+            c->lookahead = 0;
+            (void)hipGetLastError();
+        }
+    }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     *h = c;
     return 0;
@@ -65,7 +86,10 @@ int pg_create(pg_handle* h) {
 int pg_destroy(pg_handle h) {
     if (!h) return 0;
     (void)hipStreamDestroy(h->aux);
+    if (h->upd) (void)hipStreamDestroy(h->upd);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
+    free(h->pool);
     delete h;
     return 0;
 }
@@ -117,14 +141,14 @@ int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, i
              pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info));
 }
 
-int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* y, void* x,
-                 void* stream) {
-    NEED(h && L && inv_diag && y && x, "null pointer");
+int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
+                 void* work, void* stream) {
+    NEED(h && L && inv_diag && y && x && work, "null pointer");
     DISPATCH(dtype,
              pg_potrs_vec_t<double>(h, ST(stream), n, (const double*)L, ldl, (const double*)inv_diag, (const double*)y,
-                                    (double*)x),
+                                    (double*)x, (double*)work),
              pg_potrs_vec_t<float>(h, ST(stream), n, (const float*)L, ldl, (const float*)inv_diag, (const float*)y,
-                                   (float*)x));
+                                   (float*)x, (float*)work));
 }
 
 int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Minv, long ldm,
@@ -230,6 +254,12 @@ int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
     DISPATCH(dtype, pg_tril_t<double>(ST(stream), n, (double*)A, lda), pg_tril_t<float>(ST(stream), n, (float*)A, lda));
 }
 
+int pg_set_lookahead(pg_handle h, int on) {
+    NEED(h, "null handle");
+    h->lookahead = (on && h->upd) ? 1 : 0;
+    return 0;
+}
+
 int pg_profile(pg_handle h, int on) {
     NEED(h, "null handle");
     if (on) { h->prof_flops = 0; h->prof_ms = 0; h->prof_launches = 0; }
@@ -248,7 +278,7 @@ int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double
                 const void* B, long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream) {
     NEED(h && A && B && C, "null pointer");
     NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
-             variant == GEMM_TT_128,
+             variant == GEMM_TT_128 || variant == GEMM_NT_64,
          "variant not exposed");
     DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),
              gemm_raw_t<float>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream));

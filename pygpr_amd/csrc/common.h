@@ -6,6 +6,7 @@
 #include "pygpr_hip.h"
 
 #define PG_TILE 128      // GEMM block tile and Cholesky leaf size
+#define PG_RESERVED_CUS 8
 #define PG_PAD 256       // every matrix dimension handed to the O(n^3) kernels is a multiple of this
 
 
@@ -13,8 +14,13 @@ typedef double pg_d4 __attribute__((ext_vector_type(4)));
 typedef float pg_f4 __attribute__((ext_vector_type(4)));
 
 struct pg_ctx {
-    hipStream_t aux;          // look-ahead / panel stream
+    hipStream_t aux;          // look-ahead / panel stream (highest priority, non-blocking)
+    hipStream_t upd;          // trailing-update stream: CU mask leaves PG_RESERVED_CUS compute units to the panel chain
+                              // (the 128x128 leaf needs a whole CU's LDS and starves beside a chip-filling SYRK)
     hipEvent_t ev[8];
+    hipEvent_t* pool;         // events for cross-stream dependencies, grown on demand
+    int npool;
+    int lookahead;            // 0 disables the two-stream Cholesky (default 1)
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;
     double prof_ms;

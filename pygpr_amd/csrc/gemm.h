@@ -29,7 +29,8 @@ enum GemmVariant {
     GEMM_NN_128 = 2,   // triangular inverse steps
     GEMM_TN_128 = 3,   // L^-T L^-1
     GEMM_NN_128_SS = 4, // C not stored: column sums of squares of the product (predictive variance)
-    GEMM_TT_128 = 5     // C = a A^T B^T (parks (L21 X11)^T in the mirrored block of the triangular inverse)
+    GEMM_TT_128 = 5,    // C = a A^T B^T (parks (L21 X11)^T in the mirrored block of the triangular inverse)
+    GEMM_NT_64 = 6      // NT with 64 x 64 block tiles (skinny outputs: 4x the workgroups of the 128 tile)
 };
 
 template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p);

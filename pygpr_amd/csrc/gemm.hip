@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     typedef Stage<T, BM, !TA> SA;   // A: K-contiguous when not transposed
     typedef Stage<T, BN, TB> SB;    // B: K-contiguous when transposed
     typedef typename Mfma<T>::acc_t acc_t;
-    constexpr int WN_ = BN / 64;    // waves along N
+    constexpr int WT = (BM * BN == 64 * 64) ? 32 : 64;   // wave tile (square); 4 waves cover BM x BN
+    constexpr int MI = WT / 16;                          // MFMA tiles per wave-tile side
+    constexpr int WN_ = BN / WT;                         // waves along N
+    static_assert((BM / WT) * (BN / WT) == 4, "4 waves must tile the block");
 
     if (p.info && *p.info != 0) return;
 
@@ -106,16 +109,16 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     const int m0 = ti * BM, n0 = tj * BN;
     int kbeg = 0, kend = p.K;
     int kbw = 0, kew = p.K;   // this wave's own useful K range (16-granular skip inside diagonal tiles)
-    if (p.klo == 1) { kbeg = m0; kbw = m0 + wm * 64; }
-    if (p.klo == 2) { kbeg = n0; kbw = n0 + wn * 64; }
-    if (p.khi == 1) { kend = min(p.K, m0 + BM); kew = min(p.K, m0 + (wm + 1) * 64); }
-    if (p.khi == 2) { kend = min(p.K, n0 + BN); kew = min(p.K, n0 + (wn + 1) * 64); }
+    if (p.klo == 1) { kbeg = m0; kbw = m0 + wm * WT; }
+    if (p.klo == 2) { kbeg = n0; kbw = n0 + wn * WT; }
+    if (p.khi == 1) { kend = min(p.K, m0 + BM); kew = min(p.K, m0 + (wm + 1) * WT); }
+    if (p.khi == 2) { kend = min(p.K, n0 + BN); kew = min(p.K, n0 + (wn + 1) * WT); }
 
-    acc_t acc[4][4];
+    acc_t acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
@@ -143,15 +146,15 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
             const T* bs = Bs + cur * SB::LDS_ELEMS;
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
-                T a[4], bq[4];
+                T a[MI], bq[MI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = SA::frag(as, wm * 64 + i * 16 + fr, kk * 4 + fk);
+                for (int i = 0; i < MI; ++i) a[i] = SA::frag(as, wm * WT + i * 16 + fr, kk * 4 + fk);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bq[j] = SB::frag(bs, wn * 64 + j * 16 + fr, kk * 4 + fk);
+                for (int j = 0; j < MI; ++j) bq[j] = SB::frag(bs, wn * WT + j * 16 + fr, kk * 4 + fk);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
+                    for (int j = 0; j < MI; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
             }
         }
         if (kt + 1 < nk) {
@@ -164,13 +167,13 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     if (EPI == 0) {
         const T alpha = p.alpha, beta = p.beta;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < MI; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * 64 + i * 16 + Mfma<T>::row(lane, r);
-                    const int col = n0 + wn * 64 + j * 16 + fr;
+                    const int row = m0 + wm * WT + i * 16 + Mfma<T>::row(lane, r);
+                    const int col = n0 + wn * WT + j * 16 + fr;
                     T* c = C + (long)row * p.ldc + col;
                     T v = alpha * acc[i][j][r];
                     if (beta != (T)0) v += beta * *c;
@@ -178,11 +181,12 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
                 }
     } else {
         // column sums of squares of this wave's 64 rows -> part[(m0/64 + wm)][col]
+        static_assert(EPI == 0 || WT == 64, "the column-sum epilogue assumes 64-row wave tiles");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MI; ++j) {
             T s = (T)0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
             s += __shfl_xor(s, 16, 64);
@@ -221,7 +225,8 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
 }
 
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
-    const int BM = (variant == GEMM_NT_RP) ? 64 : 128, BN = (variant == GEMM_NT_RP) ? 256 : 128;
+    const int BM = (variant == GEMM_NT_RP || variant == GEMM_NT_64) ? 64 : 128;
+    const int BN = (variant == GEMM_NT_RP) ? 256 : (variant == GEMM_NT_64 ? 64 : 128);
     const int tm = M / BM, tn = N / BN;
     double f = 0;
     for (int ti = 0; ti < tm; ++ti)
@@ -247,6 +252,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         case GEMM_TN_128: rc = launch<T, true, false, 128, 128, 0>(st, p); break;
         case GEMM_NN_128_SS: rc = launch<T, false, false, 128, 128, 1>(st, p); break;
         case GEMM_TT_128: rc = launch<T, true, true, 128, 128, 0>(st, p); break;
+        case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;

@@ -17,16 +17,43 @@
 #include "kbuild.h"
 
 #define KT 64
+#define TLD 65     // odd leading dimension of the LDS transpose tile: column writes are at worst 2-way conflicted
 
 template <typename T> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 
+// exp for the covariance kernels: branch-free, 2^k * P13(r) with r = x - k ln2 (two-term reduction) and the
+// Taylor polynomial to degree 13 on |r| <= ln2/2 (truncation 4e-18 relative); <= 2 ulp, subnormal results via
+// v_ldexp_f64.  Arguments are <= 0 here; anything below -800 gives 0.
+__device__ __forceinline__ double pg_exp(double x) {
+    x = fmax(x, -800.0);
+    const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                  // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);      // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);     // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);     // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);    // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);      // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);     // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);     // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);     // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);    // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);    // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+__device__ __forceinline__ float pg_exp(float x) { return expf(x); }
+
 template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, T sqd) {
-    if (kind == PG_KIND_RBF) return sig2 * exp(-sqd);
+    if (kind == PG_KIND_RBF) return sig2 * pg_exp(-sqd);
     const T s5 = (T)2.23606797749978969641;
     const T r = sqrt(sqd);
-    return sig2 * ((T)1 + s5 * r + (T)(5.0 / 3.0) * sqd) * exp(-s5 * r);
+    return sig2 * ((T)1 + s5 * r + (T)(5.0 / 3.0) * sqd) * pg_exp(-s5 * r);
 }
 
 template <typename T>
@@ -46,11 +73,13 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                                                         int symmetric, int lower_only, double jitter,
                                                         T* __restrict__ K, long ldk) {
     const int tc = blockIdx.x, tr = blockIdx.y;
-    if (lower_only && tc > tr) return;
+    // symmetric builds evaluate only tiles on/below the diagonal; lower_only == 0 also writes the mirror image
+    if (symmetric && tc > tr) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* xr = reinterpret_cast<T*>(smem_raw);
     T* xc = xr + KT * d;
     T* l2 = xc + KT * d;   // [ncomp][d] squared inverse length scales
+    T* tt = l2 + PG_MAX_COMP * d;   // [64][TLD] transposed tile for the mirrored store (symmetric, off-diagonal)
     const int tid = threadIdx.x;
     stage_points(xr, Xr, ldr, nr, tr * KT, d, tid);
     stage_points(xc, Xc, ldc, nc, tc * KT, d, tid);
@@ -103,6 +132,7 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
     double dg = jitter;
     for (int i = 0; i < spec.nnoise; ++i) { const double s = hp[spec.noise_off[i]]; dg += s * s; }
 
+    const bool mirror = symmetric && !lower_only && tc < tr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gi = tr * KT + ty * 4 + r;
@@ -116,8 +146,23 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                 if (gi >= nr || gj >= nc) val = (symmetric && gi == gj) ? (T)1 : (T)0;
                 else if (symmetric && gi == gj) val += (T)dg;
                 vec[e] = val;
+                if (mirror) tt[(v * (16 * VE) + tx * VE + e) * TLD + ty * 4 + r] = val;
             }
             *reinterpret_cast<typename VecOf<T>::type*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE) = vec;
+        }
+    }
+    if (mirror) {   // K[tc-tile rows][tr-tile cols] = transpose, read back row-wise so the stores stay 256-byte runs
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int li = ty * 4 + r;
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                typename VecOf<T>::type vec;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) vec[e] = tt[li * TLD + v * (16 * VE) + tx * VE + e];
+                *reinterpret_cast<typename VecOf<T>::type*>(K + (long)(tc * KT + li) * ldk + tr * KT + v * (16 * VE) + tx * VE) = vec;
+            }
         }
     }
 }
@@ -130,7 +175,7 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
     }
-    const size_t lds = (size_t)(2 * KT * d + spec.ncomp * d) * sizeof(T);
+    const size_t lds = (size_t)(2 * KT * d + PG_MAX_COMP * d + (symmetric && !lower_only ? KT * TLD : 0)) * sizeof(T);
     dim3 grid(cols_pad / KT, rows_pad / KT);
     hipLaunchKernelGGL(pg_kbuild_kernel<T>, grid, dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
                        symmetric, lower_only, jitter, K, ldk);
@@ -167,12 +212,12 @@ __global__ __launch_bounds__(256) void pg_kgrad_kernel(pg_covspec spec, const do
         }
         T kv, base, coef;
         if (spec.kind[cp] == PG_KIND_RBF) {
-            kv = (T)(sg * sg) * exp(-sq);
+            kv = (T)(sg * sg) * pg_exp(-sq);
             base = kv;
             coef = (T)-2;
         } else {
             const T s5 = (T)2.23606797749978969641;
-            const T rr = sqrt(sq), ex = exp(-s5 * rr);
+            const T rr = sqrt(sq), ex = pg_exp(-s5 * rr);
             kv = (T)(sg * sg) * ((T)1 + s5 * rr + (T)(5.0 / 3.0) * sq) * ex;
             base = (T)(sg * sg) * ((T)1 + s5 * rr) * ex;
             coef = (T)(-5.0 / 3.0);
@@ -263,11 +308,11 @@ __global__ __launch_bounds__(256) void pg_grad_kernel(pg_covspec spec, const dou
             }
             double kv, base;   // dK/dl_k = base * l_k * D_k^2 (sign and constants applied in the reduce)
             if (kind == PG_KIND_RBF) {
-                kv = (double)(sig2 * exp(-sq));
+                kv = (double)(sig2 * pg_exp(-sq));
                 base = kv;
             } else {
                 const T s5 = (T)2.23606797749978969641;
-                const T rr = sqrt(sq), ex = exp(-s5 * rr);
+                const T rr = sqrt(sq), ex = pg_exp(-s5 * rr);
                 kv = (double)(sig2 * ((T)1 + s5 * rr + (T)(5.0 / 3.0) * sq) * ex);
                 base = (double)(sig2 * ((T)1 + s5 * rr) * ex);
             }

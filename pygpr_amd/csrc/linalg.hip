@@ -1,31 +1,35 @@
 // Host drivers of the blocked algorithms plus the small bandwidth-bound kernels around the MFMA core.
 //
-// potrf  : two-level right-looking (outer 1024 / inner 256).  Each inner step: two 128x128 LDS leaves
-//          (leaf.hip) give L_kk and inv(L_kk); the panel solve is a GEMM against that inverse
-//          (B <- B inv(L_kk)^T, in place, one workgroup per 64 rows); the rest of the outer panel is
-//          updated with K = 256; the trailing matrix gets one lower-tile SYRK with K = 1024 per outer panel.
+// potrf  : two-level.  Outer panels of NBO = 1024 columns; inside a panel, left-looking steps of 128 columns:
+//            U: this 128-column block -= (earlier columns of the panel) x (their rows of the block)^T   (skinny GEMM)
+//            leaf: 128x128 LDS factorisation + inverse of the diagonal block (leaf.hip)
+//            T: rows below <- rows below x inv(L_kk)^T, in place (each workgroup owns 128 full rows)
+//          then ONE lower-tile SYRK with K = 1024 on the trailing matrix, so C is re-read once per 1024 columns.
 // trtri  : Minv = L^-1 by recursive doubling over the diagonal: X21 = -X22 (L21 X11); all pairs of one
 //          level run in one batched launch; the product L21 X11 is parked (transposed) in the mirrored
 //          upper block, so no workspace is needed.
 // lauum  : K^-1 = Minv^T Minv as ONE lower-tile launch with per-tile K ranges (out of place).
+// potrs  : blocked substitution with the 128x128 diagonal inverses, one fused kernel per block step.
 #include "gemm.h"
 #include "leaf.h"
 #include "linalg.h"
 #include <cmath>
+#include <cstdlib>
 
-#define NB 256
+#define NB 128      // diagonal block / leaf size; inv_diag holds [n/128][128][128]
+#define NBO 1024    // outer panel of the Cholesky
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void copy_blocks_kernel(const T* __restrict__ src, T* __restrict__ dst, long ldd) {
-    // dst diagonal block b (256x256) <- src[b][256][256]
+    // dst diagonal block b (128x128) <- src[b][128][128]
     const int b = blockIdx.x;
     const T* s = src + (long)b * NB * NB;
     T* d = dst + (long)b * NB * ldd + (long)b * NB;
     for (int idx = blockIdx.y * 256 + threadIdx.x; idx < NB * NB; idx += gridDim.y * 256)
-        d[(long)(idx >> 8) * ldd + (idx & 255)] = s[idx];
+        d[(long)(idx >> 7) * ldd + (idx & 127)] = s[idx];
 }
 
 template <typename T> __global__ __launch_bounds__(256) void tril_kernel(T* __restrict__ A, long lda, int n) {
@@ -37,59 +41,87 @@ template <typename T> __global__ __launch_bounds__(256) void tril_kernel(T* __re
     }
 }
 
-// x_b <- op(D_b) x_b for one 256x256 diagonal-block inverse (in place through LDS)
+// Forward step b of L z = y:  z_b = inv(L_bb) w_b (every workgroup recomputes it: 128x128 matvec), workgroup 0
+// stores z_b, and workgroup g updates its 64 rows below:  w[i] -= sum_k L[i][b*128 + k] z_b[k].
+// All global loads of a phase are issued before the first reduction (the loops are latency-bound otherwise).
 template <typename T>
-__global__ __launch_bounds__(256) void blk_matvec_kernel(const T* __restrict__ D, T* __restrict__ x, int trans) {
-    __shared__ double xs[NB];
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const T* __restrict__ L, long ldl, const T* __restrict__ invb,
+                                                            int b, int n, T* __restrict__ w, T* __restrict__ z) {
+    __shared__ double ws[NB], zs[NB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    xs[tid] = (double)x[tid];
-    __syncthreads();
-    if (trans) {   // out[j] = sum_i D[i][j] x[i]   (thread per column, coalesced rows)
-        double s = 0.0;
-        for (int i = tid; i < NB; ++i) s += (double)D[(long)i * NB + tid] * xs[i];   // D lower: i >= j
-        x[tid] = (T)s;
-    } else {       // out[i] = sum_j D[i][j] x[j]   (wave per row)
-        for (int r = 0; r < 64; ++r) {
-            const int i = wave * 64 + r;
-            double s = 0.0;
-            for (int j = lane; j <= i; j += 64) s += (double)D[(long)i * NB + j] * xs[j];
-            s = wave_sum(s);
-            if (lane == 0) x[i] = (T)s;
-        }
-    }
-}
-
-// forward: y[i] -= sum_k L[i][c0 + k] z[k] for rows i >= r0 (wave per row, 64 rows per workgroup)
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_fwd_update_kernel(const T* __restrict__ L, long ldl, int c0, int r0, int n,
-                                                              T* __restrict__ y) {
-    __shared__ double zs[NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    zs[tid] = (double)y[c0 + tid];
-    __syncthreads();
-    for (int r = 0; r < 16; ++r) {
-        const int i = r0 + blockIdx.x * 64 + wave * 16 + r;
-        if (i >= n) break;
-        const T* row = L + (long)i * ldl + c0;
-        double s = 0.0;
+    const int c0 = b * NB;
+    if (tid < NB) ws[tid] = (double)w[c0 + tid];
+    // update rows of this workgroup: prefetch their L entries while the diagonal solve runs
+    const int r0 = c0 + NB + blockIdx.x * 64 + wave * 16;
+    T l0[16], l1[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += (double)row[lane + 64 * q] * zs[lane + 64 * q];
+    for (int r = 0; r < 16; ++r) {
+        const int i = r0 + r;
+        const T* row = L + (long)min(i, n - 1) * ldl + c0;
+        l0[r] = row[lane];
+        l1[r] = row[lane + 64];
+    }
+    // diagonal inverse (lower triangular): wave handles 32 rows, lane handles columns lane, lane + 64
+    T d0[32], d1[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const T* row = invb + (long)(wave * 32 + r) * NB;
+        d0[r] = row[lane];
+        d1[r] = row[lane + 64];
+    }
+    __syncthreads();
+    const double w0 = ws[lane], w1 = ws[lane + 64];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int i = wave * 32 + r;
+        double s = (lane <= i ? (double)d0[r] * w0 : 0.0) + (lane + 64 <= i ? (double)d1[r] * w1 : 0.0);
         s = wave_sum(s);
-        if (lane == 0) y[i] = (T)((double)y[i] - s);
+        if (lane == 0) zs[i] = s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < NB) z[c0 + tid] = (T)zs[tid];
+    const double z0 = zs[lane], z1 = zs[lane + 64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = r0 + r;
+        double s = (double)l0[r] * z0 + (double)l1[r] * z1;
+        s = wave_sum(s);
+        if (lane == 0 && i < n) w[i] = (T)((double)w[i] - s);
     }
 }
 
-// backward: z[j] -= sum_i L[r0 + i][j] a[i] for columns j < r0 (thread per column)
+// Backward step b of L^T a = z:  a_b = inv(L_bb)^T z_b, workgroup 0 stores a_b, workgroup g updates its 256
+// columns to the left:  z[j] -= sum_i L[b*128 + i][j] a_b[i].
 template <typename T>
-__global__ __launch_bounds__(256) void trsv_bwd_update_kernel(const T* __restrict__ L, long ldl, int r0, T* __restrict__ z) {
-    __shared__ double as[NB];
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const T* __restrict__ L, long ldl, const T* __restrict__ invb,
+                                                            int b, T* __restrict__ z, T* __restrict__ a) {
+    __shared__ double zs[NB], as[NB], part[NB];
     const int tid = threadIdx.x;
-    as[tid] = (double)z[r0 + tid];
+    const int c0 = b * NB;
+    if (tid < NB) zs[tid] = (double)z[c0 + tid];
     __syncthreads();
+    {   // column j = tid & 127; the 128 rows are split in two halves over the 256 threads (inv is lower: i >= j)
+        const int j = tid & (NB - 1), half = tid >> 7;
+        double s = 0.0;
+#pragma unroll 16
+        for (int q = 0; q < 64; ++q) {
+            const int i = half * 64 + q;
+            const double v = (double)invb[(long)i * NB + j];
+            s += (i >= j) ? v * zs[i] : 0.0;
+        }
+        if (half) part[j] = s;
+        __syncthreads();
+        if (!half) as[j] = s + part[j];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < NB) a[c0 + tid] = (T)as[tid];
     const int j = blockIdx.x * 256 + tid;
-    double s = 0.0;
-    for (int i = 0; i < NB; ++i) s += (double)L[(long)(r0 + i) * ldl + j] * as[i];
-    z[j] = (T)((double)z[j] - s);
+    if (j < c0) {
+        double s = 0.0;
+#pragma unroll 32
+        for (int i = 0; i < NB; ++i) s += (double)L[(long)(c0 + i) * ldl + j] * as[i];
+        z[j] = (T)((double)z[j] - s);
+    }
 }
 
 // part[rc][j] = sum_{i in row chunk rc} A[i][j] x[i]; tri: skip chunks above the diagonal
@@ -104,9 +136,12 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T* __restrict
     __syncthreads();
     const int j = cc * 256 + tid;
     const T* a = A + (long)rc * 256 * lda + j;
+    // lower-triangular operand: inside the diagonal chunk only rows of this column's 128-block and below count
+    // (the mirrored 128-blocks above it are scratch of the triangular inverse)
+    const int i0 = (tri && rc == cc) ? (tid & 128) : 0;
     double s = 0.0;
 #pragma unroll 8
-    for (int i = 0; i < 256; ++i) s += (double)a[(long)i * lda] * xs[i];
+    for (int i = i0; i < 256; ++i) s += (double)a[(long)i * lda] * xs[i];
     part[(long)rc * ldp + j] = (T)s;
 }
 
@@ -121,7 +156,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ pa
     out[j] = (T)(a + b * s);
 }
 
-// y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 256-block (lower-triangular M)
+// y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 128-block (lower-triangular M)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ M, long ldm, int n, const T* __restrict__ x,
                                                      T* __restrict__ y) {
@@ -201,102 +236,132 @@ template <typename T> static GemmP<T> gp0() {
     return p;
 }
 
-long pg_potrf_worksize_impl(int n) { return (long)n * NB + 128 * 128; }
+long pg_potrf_worksize_impl(int n) { return (long)n * NB; }
 
-// Factor the 256x256 diagonal block at k0 (two LDS leaves + three single-tile GEMMs) and assemble its inverse.
-template <typename T>
-static int diag_block(pg_ctx* ctx, hipStream_t st, T* A, long lda, int k0, T* inv, T* scratch, int* info) {
-    T* Akk = A + (long)k0 * lda + k0;
-    T* A21 = Akk + 128 * lda;
-    T* A22 = A21 + 128;
-    T* inv22 = inv + 128 * NB + 128;
-    int rc;
-    if ((rc = pg_leaf<T>(st, Akk, lda, inv, NB, info, k0))) return rc;
-    GemmP<T> p = gp0<T>();
-    p.info = info;
-    // A21 <- A21 inv11^T
-    p.M = p.N = p.K = 128; p.A = A21; p.lda = lda; p.B = inv; p.ldb = NB; p.C = A21; p.ldc = lda; p.khi = 2;
-    if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
-    // A22 -= A21 A21^T
-    p.khi = 0; p.B = A21; p.ldb = lda; p.C = A22; p.alpha = (T)-1; p.beta = (T)1;
-    if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
-    if ((rc = pg_leaf<T>(st, A22, lda, inv22, NB, info, k0 + 128))) return rc;
-    // inv21 = -inv22 (L21 inv11): scratch = (L21 inv11)^T = inv11^T L21^T, then NT against it
-    p = gp0<T>(); p.info = info;
-    p.M = p.N = p.K = 128; p.A = inv; p.lda = NB; p.B = A21; p.ldb = lda; p.C = scratch; p.ldc = 128; p.klo = 1;
-    if ((rc = pg_gemm<T>(ctx, st, GEMM_TT_128, p))) return rc;
-    p.klo = 0; p.khi = 1; p.A = inv22; p.lda = NB; p.B = scratch; p.ldb = 128; p.C = inv + 128 * NB; p.ldc = NB;
-    p.alpha = (T)-1;
-    return pg_gemm<T>(ctx, st, GEMM_NT_128, p);
+static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
+    if (idx >= ctx->npool) {
+        const int want = idx + 16;
+        hipEvent_t* p = (hipEvent_t*)realloc(ctx->pool, sizeof(hipEvent_t) * want);
+        if (!p) { pg_set_error("out of memory for events"); return -3; }
+        ctx->pool = p;
+        for (int i = ctx->npool; i < want; ++i) PG_CHECK(hipEventCreateWithFlags(&ctx->pool[i], hipEventDisableTiming));
+        ctx->npool = want;
+    }
+    *ev = ctx->pool[idx];
+    return 0;
 }
 
-// Two-level right-looking Cholesky: inner steps of NB = 256 columns (diagonal block, panel solve against its
-// inverse, update of the REST OF THE OUTER PANEL only), and one lower-tile SYRK with K = NBO per outer panel, so
-// the big trailing update re-reads/re-writes C once per NBO columns instead of once per 256.
-#define NBO 1024
+// Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
+// panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
+//   panel stream (handle's high-priority stream):  Chain(0) Sa(0) Chain(1) [wait Sb(0)] Sa(1) Chain(2) ...
+//   update stream (handle's CU-masked stream)   :           [wait Chain(0)] Sb(0) [wait Chain(1)] Sb(1) ...
+// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap; Sa(o) and
+// Sb(o-1) both read-modify-write panel o+1's columns, hence the wait.  Everything is joined back onto the caller's
+// stream at the end.
 template <typename T>
 int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info) {
-    if (n <= 0 || n % NB) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, NB); return -2; }
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
-    PG_CHECK(hipMemsetAsync(invD, 0, (size_t)pg_potrf_worksize_impl(n) * sizeof(T), st));
-    T* scratch = invD + (long)n * NB;   // 128 x 128
+    const int npan = (n + NBO - 1) / NBO;
+    const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
+    hipStream_t ps = la ? ctx->aux : st;   // panel stream
+    hipStream_t us = la ? ctx->upd : st;   // update stream (CU-masked so the leaf always finds a free CU)
+    hipEvent_t ev;
     int rc;
-    for (int o0 = 0; o0 < n; o0 += NBO) {
-        const int oend = std::min(n, o0 + NBO);
-        for (int k0 = o0; k0 < oend; k0 += NB) {
-            T* inv = invD + (long)(k0 / NB) * NB * NB;
-            if ((rc = diag_block<T>(ctx, st, A, lda, k0, inv, scratch, info))) return rc;
-            const int m = n - k0 - NB;
-            if (m <= 0) continue;
-            T* P = A + (long)(k0 + NB) * lda + k0;          // rows below the diagonal block, 256 columns
+    if (la) {
+        if ((rc = pool_event(ctx, 0, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, st));
+        PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+        PG_CHECK(hipStreamWaitEvent(us, ev, 0));
+    }
+    int last_sb = -1;
+    for (int o = 0; o < npan; ++o) {
+        const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
+        if (o > 0) {   // Sa(o-1): this panel's columns -= previous panel
+            if (la && o >= 2) {
+                if ((rc = pool_event(ctx, 2 + 2 * (o - 2) + 1, &ev))) return rc;   // ev_sb[o-2]
+                PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+            }
+            const int p0 = o0 - NBO;
             GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = m; p.N = NB; p.K = NB; p.A = P; p.lda = lda; p.B = inv; p.ldb = NB; p.C = P; p.ldc = lda; p.khi = 2;
-            if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_RP, p))) return rc;
-            const int w = oend - k0 - NB;                   // columns of the outer panel still to be factored
-            if (w > 0) {
-                p = gp0<T>(); p.info = info;
-                p.M = m; p.N = w; p.K = NB; p.A = P; p.lda = lda; p.B = P; p.ldb = lda; p.C = P + NB; p.ldc = lda;
+            p.M = n - o0; p.N = oend - o0; p.K = NBO;
+            p.A = A + (long)o0 * lda + p0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o0 * lda + o0; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1;
+            if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_128, p))) return rc;
+        }
+        for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
+            T* Akk = A + (long)k0 * lda + k0;
+            T* inv = invD + (long)(k0 / NB) * NB * NB;
+            if (k0 > o0) {   // U: bring this column block up to date with the panel's earlier columns
+                GemmP<T> p = gp0<T>(); p.info = info;
+                p.M = n - k0; p.N = NB; p.K = k0 - o0;
+                p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
                 p.alpha = (T)-1; p.beta = (T)1;
-                if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64, p))) return rc;
+            }
+            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
+            const int m = n - k0 - NB;
+            if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 128 full rows)
+                GemmP<T> p = gp0<T>(); p.info = info;
+                p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
+                p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
+                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_128, p))) return rc;
             }
         }
-        const int m = n - oend;
-        if (m > 0) {
-            T* P = A + (long)oend * lda + o0;               // m x (oend - o0): final L values of this outer panel
+        if (la) {
+            if ((rc = pool_event(ctx, 2 + 2 * o, &ev))) return rc;       // ev_chain[o]
+            PG_CHECK(hipEventRecord(ev, ps));
+        }
+        const int o2 = std::min(n, oend + NBO);   // first column right of panel o+1
+        const int m2 = n - o2;
+        if (m2 > 0) {  // Sb(o)
+            if (la) PG_CHECK(hipStreamWaitEvent(us, ev, 0));
+            T* P = A + (long)o2 * lda + o0;
             GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = p.N = m; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
-            p.C = A + (long)oend * lda + oend; p.ldc = lda;
+            p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
+            p.C = A + (long)o2 * lda + o2; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
-            if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+            if ((rc = pg_gemm<T>(ctx, us, GEMM_NT_128, p))) return rc;
+            if (la) {
+                if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]
+                PG_CHECK(hipEventRecord(ev, us));
+                last_sb = o;
+            }
+        }
+    }
+    if (la) {
+        if ((rc = pool_event(ctx, 1, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, ps));
+        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+        if (last_sb >= 0) {
+            if ((rc = pool_event(ctx, 2 + 2 * last_sb + 1, &ev))) return rc;
+            PG_CHECK(hipStreamWaitEvent(st, ev, 0));
         }
     }
     return 0;
 }
 
 template <typename T>
-int pg_potrs_vec_t(pg_ctx*, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x) {
-    if (n <= 0 || n % NB) { pg_set_error("pg_potrs_vec: n=%d is not a positive multiple of %d", n, NB); return -2; }
-    if (x != y) PG_CHECK(hipMemcpyAsync(x, y, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st));
+int pg_potrs_vec_t(pg_ctx*, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work) {
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrs_vec: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    T* w = work;          // running right-hand side of the forward sweep
+    T* z = work + n;      // forward result / running right-hand side of the backward sweep
+    PG_CHECK(hipMemcpyAsync(w, y, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st));
     const int nb = n / NB;
-    for (int b = 0; b < nb; ++b) {   // L z = y
-        hipLaunchKernelGGL(blk_matvec_kernel<T>, dim3(1), dim3(256), 0, st, invD + (long)b * NB * NB, x + b * NB, 0);
-        const int r0 = (b + 1) * NB;
-        if (r0 < n)
-            hipLaunchKernelGGL(trsv_fwd_update_kernel<T>, dim3((n - r0) / 64), dim3(256), 0, st, L, ldl, b * NB, r0, n, x);
-    }
-    for (int b = nb - 1; b >= 0; --b) {   // L^T a = z
-        hipLaunchKernelGGL(blk_matvec_kernel<T>, dim3(1), dim3(256), 0, st, invD + (long)b * NB * NB, x + b * NB, 1);
-        if (b > 0)
-            hipLaunchKernelGGL(trsv_bwd_update_kernel<T>, dim3(b), dim3(256), 0, st, L, ldl, b * NB, x);
-    }
+    for (int b = 0; b < nb; ++b)      // L z = y
+        hipLaunchKernelGGL(trsv_fwd_step_kernel<T>, dim3(std::max(1, (n - (b + 1) * NB) / 64)), dim3(256), 0, st, L, ldl,
+                           invD + (long)b * NB * NB, b, n, w, z);
+    for (int b = nb - 1; b >= 0; --b) // L^T a = z
+        hipLaunchKernelGGL(trsv_bwd_step_kernel<T>, dim3(std::max(1, (b * NB + 255) / 256)), dim3(256), 0, st, L, ldl,
+                           invD + (long)b * NB * NB, b, z, x);
     LAUNCH_CHECK();
     return 0;
 }
 
 template <typename T>
 int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm) {
-    if (n <= 0 || n % NB) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, NB); return -2; }
-    hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 16), dim3(256), 0, st, invD, M, ldm);
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 8), dim3(256), 0, st, invD, M, ldm);
     LAUNCH_CHECK();
     // invariant: the diagonal is tiled by `nfull` inverted blocks of size h plus one smaller inverted block `rem`
     int rc;
@@ -338,7 +403,7 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
 
 template <typename T>
 int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv, long ldk) {
-    if (n <= 0 || n % NB) { pg_set_error("pg_lauum: n=%d is not a positive multiple of %d", n, NB); return -2; }
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_lauum: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     GemmP<T> p = gp0<T>();
     p.M = p.N = p.K = n; p.A = M; p.lda = ldm; p.B = M; p.ldb = ldm; p.C = Kinv; p.ldc = ldk;
     p.tri = 1; p.klo = 1;
@@ -347,7 +412,7 @@ int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv
 
 template <typename T>
 int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work) {
-    if (n <= 0 || n % NB) { pg_set_error("pg_trmv: n=%d is not a positive multiple of %d", n, NB); return -2; }
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_trmv: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     if (!trans) {
         hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((n + 15) / 16), dim3(256), 0, st, M, ldm, n, x, y);
     } else {
@@ -368,7 +433,7 @@ int pg_nlml_value_t(hipStream_t st, int n, const T* L, long ldl, const T* y, con
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, long ldks, const T* M, long ldm,
                         const T* alpha, T* mean, T* q, double kss, T* work) {
-    if (n % NB || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
+    if (n % PG_PAD || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
     hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(m / 256, n / 256), dim3(256), 0, st, Ks, ldks, alpha, work, (long)m, 0);
     hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 256, m, mean, 0, 0.0, 1.0);
     LAUNCH_CHECK();
@@ -386,7 +451,7 @@ int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, 
 
 template <typename T>
 int pg_trmm_lower_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* M, long ldm, const T* Ks, long ldks, T* V, long ldv) {
-    if (n % NB || m % 128) { pg_set_error("pg_trmm_lower: n_pad=%d m_pad=%d not aligned", n, m); return -2; }
+    if (n % PG_PAD || m % 128) { pg_set_error("pg_trmm_lower: n_pad=%d m_pad=%d not aligned", n, m); return -2; }
     GemmP<T> p = gp0<T>();
     p.M = n; p.N = m; p.K = n; p.A = M; p.lda = ldm; p.B = Ks; p.ldb = ldks; p.C = V; p.ldc = ldv; p.khi = 1;
     return pg_gemm<T>(ctx, st, GEMM_NN_128, p);
@@ -426,7 +491,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 
 #define INST(T)                                                                                                        \
     template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*);                                         \
-    template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*);                 \
+    template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long);                         \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \

@@ -9,7 +9,7 @@ import torch
 
 from oracle import pygpr_oracle as orc
 
-NB = 256
+NB = 128
 
 
 def _np(t):
@@ -81,7 +81,7 @@ class OracleOps:
 
     # factorisation
     def potrf_workspace(self, n_pad, dtype):
-        return torch.zeros(n_pad * NB + 128 * 128, dtype=dtype)
+        return torch.zeros(n_pad * NB, dtype=dtype)
 
     def potrf(self, a, invd, info):
         m = np.tril(_np(a).astype(np.float64))
@@ -95,7 +95,7 @@ class OracleOps:
             idx = np.tril_indices(m.shape[0])
             _np(a)[idx] = low[idx]
 
-    def potrs_vec(self, chol, invd, y, x):
+    def potrs_vec(self, chol, invd, y, x, work=None):
         x.copy_(torch.from_numpy(sla.cho_solve((np.tril(_np(chol).astype(np.float64)), True), _np(y).astype(np.float64),
                                               check_finite=False)))
 

@@ -188,7 +188,7 @@ def test_potrf_solves_inverse(ops, n):
     ops.trtri(ad, invd, minv)
     linv = np.linalg.inv(chol)
     got = host(minv)
-    for ti in range(n // 128):   # strictly upper 128-tiles outside the diagonal 256-blocks are scratch
+    for ti in range(n // 128):   # strictly upper 128-tiles are scratch of the recursive doubling
         for tj in range(ti + 1):
             blk = (slice(ti * 128, ti * 128 + 128), slice(tj * 128, tj * 128 + 128))
             np.testing.assert_allclose(got[blk], linv[blk], atol=1e-11)
@@ -207,6 +207,25 @@ def test_potrf_solves_inverse(ops, n):
     # tril export
     ops.tril(ad, n)
     np.testing.assert_allclose(host(ad), chol, atol=1e-12)
+
+
+def test_potrf_lookahead_matches_sequential(ops):
+    """n = 3072 spans three outer panels, so the two-stream look-ahead schedule is active; it must give the
+    same factor as the single-stream schedule (same arithmetic, different overlap) and match LAPACK."""
+    rng = np.random.default_rng(33)
+    n = 3072
+    a = spd(n, rng)
+    outs = []
+    for la in (1, 0):
+        ops.set_lookahead(la)
+        ad = dev(a)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
+        assert int(info.item()) == 0
+        outs.append(np.tril(host(ad)))
+    ops.set_lookahead(1)
+    assert np.array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0], np.linalg.cholesky(a), atol=1e-11)
 
 
 def test_potrf_not_positive_definite_reports_minor(ops):

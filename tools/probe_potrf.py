@@ -14,6 +14,7 @@ ops.kernel_build(spec, hp, x, None, k, jitter=1e-7)
 invd = ops.potrf_workspace(n, torch.float64); info = torch.zeros(1, dtype=torch.int32, device="cuda")
 minv = ops.zeros(n, n); kinv = ops.zeros(n, n)
 for _ in range(3):
-    kl.copy_(k); ops.potrf(kl, invd, info); ops.trtri(kl, invd, minv); ops.lauum(minv, kinv)
+    kl.copy_(k); ops.potrf(kl, invd, info)
+    if len(sys.argv) < 3: ops.trtri(kl, invd, minv); ops.lauum(minv, kinv)
 torch.cuda.synchronize()
 print("info", int(info.item()))
