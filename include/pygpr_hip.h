@@ -123,6 +123,15 @@ int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, cons
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g,
                     const void* var_g, void* mean, void* var, double* beta0, double* prec0, void* stream);
 
+/* Full-covariance committee (gr_bcm.py:99-114,147).  pg_grbcm_weighted_prec: acc[i][j] (+)= 1/2 (beta_i + beta_j) P[i][j]
+ * on the lower triangle for one expert's precision P = cov_c^-1 (rows >= m of a fresh acc get a unit diagonal);
+ * pg_symmetrize mirrors the lower triangle up; pg_grbcm_finish_full: mean = diag(cov) o (sum beta prec mu). */
+int pg_grbcm_weighted_prec(pg_handle h, int dtype, int m, int m_pad, const void* P, long ldp, const double* beta, void* acc,
+                           long lda, int accumulate, void* stream);
+int pg_symmetrize(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
+int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
+                         const void* cov, long ldc, void* mean, void* stream);
+
 /* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
 

@@ -51,6 +51,9 @@ _SIGS = {
     "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
     "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pg_grbcm_weighted_prec": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _i, _vp]),
+    "pg_symmetrize": (_i, [_vp, _i, _i, _vp, _l, _vp]),
+    "pg_grbcm_finish_full": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp]),
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_set_lookahead": (_i, [_vp, _i]),
     "pg_profile": (_i, [_vp, _i]),

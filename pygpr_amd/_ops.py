@@ -1,6 +1,7 @@
 """Device-op layer: torch-ROCm tensors are only buffers + the current stream; every number is
 produced by libpygpr_hip through the C ABI (include/pygpr_hip.h).  No CPU path exists here:
 `get_ops()` raises when the library or a GPU is missing."""
+import atexit
 import ctypes as C
 
 import torch
@@ -38,6 +39,16 @@ class HipOps:
         _lib.check(self.lib.pg_create(C.byref(h)), "pg_create")
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
+        atexit.register(self.close)   # destroy the handle's streams/events before the HIP runtime is torn down
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.lib.pg_destroy(self.h)
+            self.h = None
 
     # -- helpers ------------------------------------------------------------------------------
     def _st(self):
@@ -163,6 +174,32 @@ class HipOps:
         _lib.check(self.lib.pg_grbcm_finish(self.h, _code(mean_g.dtype), mean_g.numel(), _p(sums), sums.stride(0),
                                             _p(mean_g), _p(var_g), _p(mean), _p(var), _p(beta0), _p(prec0),
                                             self._st()), "pg_grbcm_finish")
+
+    def grbcm_weighted_prec(self, prec, beta, acc, m, accumulate):
+        self._chk(prec, beta, acc)
+        _lib.check(self.lib.pg_grbcm_weighted_prec(self.h, _code(acc.dtype), m, acc.shape[0], _p(prec), prec.stride(0), _p(beta),
+                                                   _p(acc), acc.stride(0), int(accumulate), self._st()), "pg_grbcm_weighted_prec")
+
+    def symmetrize(self, a, n):
+        self._chk(a)
+        _lib.check(self.lib.pg_symmetrize(self.h, _code(a.dtype), n, _p(a), a.stride(0), self._st()), "pg_symmetrize")
+
+    def grbcm_finish_full(self, sums, mean_g, var_g, cov, mean):
+        self._chk(sums, mean_g, var_g, cov, mean)
+        _lib.check(self.lib.pg_grbcm_finish_full(self.h, _code(mean_g.dtype), mean_g.numel(), _p(sums), sums.stride(0), _p(mean_g),
+                                                 _p(var_g), _p(cov), cov.stride(0), _p(mean), self._st()), "pg_grbcm_finish_full")
+
+    def spd_inverse_lower(self, a_pad):
+        """a_pad (padded SPD, lower triangle valid) -> its inverse's lower triangle in a new buffer; raises on a bad pivot."""
+        n = a_pad.shape[0]
+        invd = self.potrf_workspace(n, a_pad.dtype)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.potrf(a_pad, invd, info)
+        minv = self.empty(n, n, dtype=a_pad.dtype)
+        self.trtri(a_pad, invd, minv)
+        out = self.empty(n, n, dtype=a_pad.dtype)
+        self.lauum(minv, out)
+        return out, info
 
     # -- raw GEMM core (tests, roofline micro-benchmark) ---------------------------------------
     def gemm_raw(self, variant, m, n, k, alpha, a, b, beta, c, tri=0, klo=0, khi=0):

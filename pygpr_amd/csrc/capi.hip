@@ -39,7 +39,7 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     p.alpha = (T)alpha; p.beta = (T)beta;
     p.tri = tri; p.klo = klo; p.khi = khi;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
-    p.part = nullptr; p.ldp = 0; p.info = nullptr;
+    p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
     return pg_gemm<T>(h, ST(stream), variant, p);
 }
 
@@ -247,6 +247,29 @@ int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds,
                                        (double*)var, beta0, prec0),
              pg_grbcm_finish_t<float>(ST(stream), m, sums, lds, (const float*)mean_g, (const float*)var_g, (float*)mean,
                                       (float*)var, beta0, prec0));
+}
+
+int pg_grbcm_weighted_prec(pg_handle h, int dtype, int m, int m_pad, const void* P, long ldp, const double* beta, void* acc,
+                           long lda, int accumulate, void* stream) {
+    NEED(h && P && beta && acc, "null pointer");
+    NEED(m_pad >= m && ldp >= m && lda >= m_pad, "inconsistent sizes");
+    DISPATCH(dtype, pg_weighted_prec_t<double>(ST(stream), m, m_pad, (const double*)P, ldp, beta, (double*)acc, lda, accumulate),
+             pg_weighted_prec_t<float>(ST(stream), m, m_pad, (const float*)P, ldp, beta, (float*)acc, lda, accumulate));
+}
+
+int pg_symmetrize(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
+    NEED(h && A, "null pointer");
+    DISPATCH(dtype, pg_symmetrize_t<double>(ST(stream), n, (double*)A, lda), pg_symmetrize_t<float>(ST(stream), n, (float*)A, lda));
+}
+
+int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
+                         const void* cov, long ldc, void* mean, void* stream) {
+    NEED(h && sums && mean_g && var_g && cov && mean, "null pointer");
+    DISPATCH(dtype,
+             pg_grbcm_finish_full_t<double>(ST(stream), m, sums, lds, (const double*)mean_g, (const double*)var_g,
+                                            (const double*)cov, ldc, (double*)mean),
+             pg_grbcm_finish_full_t<float>(ST(stream), m, sums, lds, (const float*)mean_g, (const float*)var_g, (const float*)cov,
+                                           ldc, (float*)mean));
 }
 
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {

@@ -21,6 +21,7 @@ template <typename T> struct GemmP {
     T* part;          // EPI == 1: partial column sums of squares, [M/64][ldp]
     long ldp;
     const int* info;  // device flag: kernels exit at once when *info != 0 (failed factorisation)
+    int noxcd;        // 1: keep launch order instead of the XCD-chunked tile order (experiments)
 };
 
 enum GemmVariant {
@@ -30,7 +31,8 @@ enum GemmVariant {
     GEMM_TN_128 = 3,   // L^-T L^-1
     GEMM_NN_128_SS = 4, // C not stored: column sums of squares of the product (predictive variance)
     GEMM_TT_128 = 5,    // C = a A^T B^T (parks (L21 X11)^T in the mirrored block of the triangular inverse)
-    GEMM_NT_64 = 6      // NT with 64 x 64 block tiles (skinny outputs: 4x the workgroups of the 128 tile)
+    GEMM_NT_64 = 6,     // NT with 64 x 64 block tiles (skinny outputs: 4x the workgroups of the 128 tile)
+    GEMM_NT_64x128 = 7  // NT with 64 x 128 block tiles: in-place panel solve against a 128 x 128 inverse
 };
 
 template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p);

@@ -9,6 +9,7 @@
 // One 16x16x4 fp64 MFMA is 2048 flop in 64 cycles per SIMD (78.6 TFLOP/s chip peak), so a K tile is
 // 4096 MFMA cycles per wave against 8 ds_read_b64 per k-step: the loop is MFMA-bound by construction.
 #include "gemm.h"
+#include <cstdlib>
 
 #define BK 16
 
@@ -68,13 +69,13 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     typedef Stage<T, BM, !TA> SA;   // A: K-contiguous when not transposed
     typedef Stage<T, BN, TB> SB;    // B: K-contiguous when transposed
     typedef typename Mfma<T>::acc_t acc_t;
-    constexpr int WT = (BM * BN == 64 * 64) ? 32 : 64;   // wave tile (square); 4 waves cover BM x BN
-    constexpr int MI = WT / 16;                          // MFMA tiles per wave-tile side
-    constexpr int WN_ = BN / WT;                         // waves along N
-    static_assert((BM / WT) * (BN / WT) == 4, "4 waves must tile the block");
+    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : 32;   // wave tile rows; 4 waves cover BM x BN
+    constexpr int WTN = (BN == 64) ? 32 : 64;                 // wave tile columns
+    constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
+    constexpr int WN_ = BN / WTN;                             // waves along N
+    static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves must tile the block");
 
     if (p.info && *p.info != 0) return;
-
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* As = reinterpret_cast<T*>(smem_raw);
     T* Bs = As + 2 * SA::LDS_ELEMS;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     // round-robin over the XCDs, which balances the work.
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const int wg = (p.klo | p.khi) ? b : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int wg = (p.klo | p.khi | p.noxcd) ? b : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
 
     int ti, tj;
     if (p.tri) {
@@ -109,16 +110,16 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     const int m0 = ti * BM, n0 = tj * BN;
     int kbeg = 0, kend = p.K;
     int kbw = 0, kew = p.K;   // this wave's own useful K range (16-granular skip inside diagonal tiles)
-    if (p.klo == 1) { kbeg = m0; kbw = m0 + wm * WT; }
-    if (p.klo == 2) { kbeg = n0; kbw = n0 + wn * WT; }
-    if (p.khi == 1) { kend = min(p.K, m0 + BM); kew = min(p.K, m0 + (wm + 1) * WT); }
-    if (p.khi == 2) { kend = min(p.K, n0 + BN); kew = min(p.K, n0 + (wn + 1) * WT); }
+    if (p.klo == 1) { kbeg = m0; kbw = m0 + wm * WTM; }
+    if (p.klo == 2) { kbeg = n0; kbw = n0 + wn * WTN; }
+    if (p.khi == 1) { kend = min(p.K, m0 + BM); kew = min(p.K, m0 + (wm + 1) * WTM); }
+    if (p.khi == 2) { kend = min(p.K, n0 + BN); kew = min(p.K, n0 + (wn + 1) * WTN); }
 
-    acc_t acc[MI][MI];
+    acc_t acc[MIM][MIN];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MIM; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
+        for (int j = 0; j < MIN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
@@ -146,15 +147,15 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
             const T* bs = Bs + cur * SB::LDS_ELEMS;
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
-                T a[MI], bq[MI];
+                T a[MIM], bq[MIN];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = SA::frag(as, wm * WT + i * 16 + fr, kk * 4 + fk);
+                for (int i = 0; i < MIM; ++i) a[i] = SA::frag(as, wm * WTM + i * 16 + fr, kk * 4 + fk);
 #pragma unroll
-                for (int j = 0; j < MI; ++j) bq[j] = SB::frag(bs, wn * WT + j * 16 + fr, kk * 4 + fk);
+                for (int j = 0; j < MIN; ++j) bq[j] = SB::frag(bs, wn * WTN + j * 16 + fr, kk * 4 + fk);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MIM; ++i)
 #pragma unroll
-                    for (int j = 0; j < MI; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
+                    for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
             }
         }
         if (kt + 1 < nk) {
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     if (EPI == 0) {
         const T alpha = p.alpha, beta = p.beta;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MIM; ++i)
 #pragma unroll
-            for (int j = 0; j < MI; ++j)
+            for (int j = 0; j < MIN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * WT + i * 16 + Mfma<T>::row(lane, r);
-                    const int col = n0 + wn * WT + j * 16 + fr;
+                    const int row = m0 + wm * WTM + i * 16 + Mfma<T>::row(lane, r);
+                    const int col = n0 + wn * WTN + j * 16 + fr;
                     T* c = C + (long)row * p.ldc + col;
                     T v = alpha * acc[i][j][r];
                     if (beta != (T)0) v += beta * *c;
@@ -181,12 +182,12 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
                 }
     } else {
         // column sums of squares of this wave's 64 rows -> part[(m0/64 + wm)][col]
-        static_assert(EPI == 0 || WT == 64, "the column-sum epilogue assumes 64-row wave tiles");
+        static_assert(EPI == 0 || (WTM == 64 && WTN == 64), "the column-sum epilogue assumes 64 x 64 wave tiles");
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
+        for (int j = 0; j < MIN; ++j) {
             T s = (T)0;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MIM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
             s += __shfl_xor(s, 16, 64);
@@ -225,7 +226,7 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
 }
 
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
-    const int BM = (variant == GEMM_NT_RP || variant == GEMM_NT_64) ? 64 : 128;
+    const int BM = (variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128) ? 64 : 128;
     const int BN = (variant == GEMM_NT_RP) ? 256 : (variant == GEMM_NT_64 ? 64 : 128);
     const int tm = M / BM, tn = N / BN;
     double f = 0;
@@ -241,7 +242,10 @@ double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi
     return f * batch;
 }
 
-template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p) {
+template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p_in) {
+    static const int noxcd = getenv("PG_NOXCD") ? atoi(getenv("PG_NOXCD")) : 0;
+    GemmP<T> p = p_in;
+    p.noxcd = noxcd;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;
@@ -253,6 +257,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         case GEMM_NN_128_SS: rc = launch<T, false, false, 128, 128, 1>(st, p); break;
         case GEMM_TT_128: rc = launch<T, true, true, 128, 128, 0>(st, p); break;
         case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;
+        case GEMM_NT_64x128: rc = launch<T, false, true, 64, 128, 0>(st, p); break;
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;

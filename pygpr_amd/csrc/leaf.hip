@@ -1,13 +1,15 @@
 // Cholesky leaf: factor one 128x128 diagonal block entirely in LDS (one 256-thread workgroup) and produce
 // its inverse, which turns every triangular solve above it into an MFMA GEMM.
 //
-// Blocked right-looking with 16-wide micro-panels; per micro-panel jb:
-//   A. wave 0 factors the 16x16 diagonal block in REGISTERS (lane r holds row r; pivots and multipliers
-//      are broadcast with v_readlane, 1/sqrt by v_rsq + 2 Newton steps) and inverts it the same way
-//      (lane c solves column c).  A non-positive / NaN pivot sets *info = global column + 1 (LAPACK
-//      convention, first failure wins) and stops.
+// Blocked right-looking with 16-wide micro-panels, software-pipelined; per micro-panel jb:
+//   A. wave 0 factors the 16x16 diagonal block AND inverts it in one pass over its columns, in REGISTERS: lane r
+//      holds row r of D and row r of X = D^-1; per column the pivot, the multipliers and the finished row c of X
+//      are broadcast with v_readlane (1/sqrt by v_rsq + 2 Newton steps).  A non-positive / NaN pivot sets
+//      *info = global column + 1 (LAPACK convention, first failure wins) and stops.
+//      Meanwhile waves 1..3 finish the trailing update of the PREVIOUS micro-panel (all tiles except its first
+//      tile column), which nothing in A or B depends on.
 //   B. panel solve  P <- P inv(D)^T  for the rows below, 16x16x4 MFMAs on LDS operands
-//   C. trailing update  T <- T - P P^T  (lower 16x16 tiles), MFMA with the tile as the accumulator
+//   C. first tile column of the trailing update  T <- T - P P^T  (next diagonal block + next panel), MFMA
 // The inverse of the whole block then follows by recursive doubling from the eight 16x16 inverses:
 // X21 = -X22 (L21 X11), level by level (16, 32, 64), again MFMA on LDS; the mirrored (upper) block is
 // the scratch for L21 X11.  LDS: S[128][130] + 8 x [16][18] inverses, all in the dynamic region.
@@ -40,26 +42,31 @@ __device__ __forceinline__ float inv_sqrt(float x) {
 }
 
 // C(16x16) = beta * C + alpha * A(16xK) * op(B); A row-major [16][K] at lda; B either [K][16] (TB = false)
-// or [16][K] (TB = true) at ldb; all in LDS.  One wave.
+// or [16][K] (TB = true) at ldb; all in LDS.  One wave.  Fragments are read 16 k at a time ahead of the MFMAs
+// (and the C tile up front) so the LDS latency is paid once per group instead of once per k-step.
 template <typename T, bool TB>
 __device__ __forceinline__ void lds_tile_mm(T* C, int ldc, const T* A, int lda, const T* B, int ldb, int K, T alpha,
                                             T beta, int lane) {
     typename Mfma<T>::acc_t acc;
     const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
-    for (int k = 0; k < K; k += 4) {
-        const T a = A[fr * lda + k + fk];
-        const T b = TB ? B[fr * ldb + k + fk] : B[(k + fk) * ldb + fr];
-        acc = Mfma<T>::run(a, b, acc);
-    }
+    T cin[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        T* c = C + Mfma<T>::row(lane, r) * ldc + fr;
-        T v = alpha * acc[r];
-        if (beta != (T)0) v += beta * *c;
-        *c = v;
+        acc[r] = (T)0;
+        cin[r] = (beta != (T)0) ? C[Mfma<T>::row(lane, r) * ldc + fr] : (T)0;
     }
+    for (int k = 0; k < K; k += 16) {
+        T a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = A[fr * lda + k + 4 * q + fk];
+            b[q] = TB ? B[fr * ldb + k + 4 * q + fk] : B[(k + 4 * q + fk) * ldb + fr];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = Mfma<T>::run(a[q], b[q], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[Mfma<T>::row(lane, r) * ldc + fr] = alpha * acc[r] + beta * cin[r];
 }
 
 template <typename T>
@@ -73,21 +80,27 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
 
     if (*info != 0) return;
     if (tid == 0) fail = 0;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx >> 7, k = idx & 127;
-        S[i * LD + k] = (k <= i) ? A[(long)i * lda + k] : (T)0;
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {       // two columns per thread, 64 pairs per row
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        pair_t v = {(T)0, (T)0};
+        if (k <= i) {
+            v = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
+            if (k + 1 > i) v[1] = (T)0;
+        }
+        *reinterpret_cast<pair_t*>(S + i * LD + k) = v;
     }
     __syncthreads();
 
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
-        // ---- A: diagonal 16x16 block, registers of wave 0
         if (wave == 0) {
+            // ---- A: diagonal 16x16 block: factor + inverse fused, registers of wave 0
             const int r = lane & 15;
             T* D = S + c0 * LD + c0;
-            T row[16], rdiag[16];
+            T row[16], xr[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) row[c] = D[r * LD + c];
+            for (int c = 0; c < 16; ++c) { row[c] = D[r * LD + c]; xr[c] = (c == r) ? (T)1 : (T)0; }
             bool ok = true;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -97,29 +110,38 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
                     if (lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + c + 1); }
                 }
                 const T rs = ok ? inv_sqrt(piv) : (T)0;
-                rdiag[c] = rs;
-                const T lrc = row[c] * rs;
+                const T lrc = row[c] * rs;           // lane c: sqrt(piv); lanes r < c: 0 (upper part is zero)
                 row[c] = lrc;
+                const T mult = (r > c) ? lrc : (T)0;
 #pragma unroll
                 for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
-            }
-            if (lane < 16) {
+                // row c of X is complete once scaled by 1/l_cc; rows below eliminate it
 #pragma unroll
-                for (int c = 0; c < 16; ++c) D[r * LD + c] = (c <= r) ? row[c] : (T)0;
-            }
-            // inverse: lane c (0..15) solves L x = e_c; L[i][k] lives in lane i's row[k]
-            T x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                T s = (i == r) ? (T)1 : (T)0;
-#pragma unroll
-                for (int k = 0; k < i; ++k) s -= bcast_lane(row[k], i) * x[k];
-                x[i] = s * rdiag[i];
+                for (int j = 0; j <= c; ++j) {
+                    const T xc = bcast_lane(xr[j], c) * rs;
+                    xr[j] = (r == c) ? xc : xr[j] - mult * xc;
+                }
             }
             if (lane < 16) {
                 T* Dv = Dinv + jb * 16 * DLD;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) Dv[i * DLD + r] = x[i];
+                for (int c = 0; c < 16; ++c) {
+                    D[r * LD + c] = (c <= r) ? row[c] : (T)0;
+                    Dv[r * DLD + c] = (c <= r) ? xr[c] : (T)0;
+                }
+            }
+        } else if (jb > 0) {
+            // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti
+            const int pc0 = c0 - 16, pr0 = c0;           // previous panel's columns / first trailing row
+            const int pnt = (NB - pr0) / 16;
+            const int nrest = pnt * (pnt - 1) / 2;       // pairs (ti, tj): 1 <= tj <= ti <= pnt - 1
+            for (int t = wave - 1; t < nrest; t += 3) {
+                int u = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (u * (u + 1) / 2 > t) --u;
+                while ((u + 1) * (u + 2) / 2 <= t) ++u;
+                const int ti = u + 1, tj = t - u * (u + 1) / 2 + 1;
+                lds_tile_mm<T, true>(S + (pr0 + ti * 16) * LD + pr0 + tj * 16, LD, S + (pr0 + ti * 16) * LD + pc0, LD,
+                                     S + (pr0 + tj * 16) * LD + pc0, LD, 16, (T)-1, (T)1, lane);
             }
         }
         __syncthreads();
@@ -131,23 +153,20 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
             lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + c0, LD, S + (r0 + t * 16) * LD + c0, LD, Dinv + jb * 16 * DLD,
                                  DLD, 16, (T)1, (T)0, lane);
         __syncthreads();
-        // ---- C: T <- T - P P^T on the lower tiles
-        const int ntri = nt * (nt + 1) / 2;
-        for (int t = wave; t < ntri; t += 4) {
-            int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (ti * (ti + 1) / 2 > t) --ti;
-            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-            const int tj = t - ti * (ti + 1) / 2;
-            lds_tile_mm<T, true>(S + (r0 + ti * 16) * LD + r0 + tj * 16, LD, S + (r0 + ti * 16) * LD + c0, LD,
-                                 S + (r0 + tj * 16) * LD + c0, LD, 16, (T)-1, (T)1, lane);
-        }
+        // ---- C (first tile column): next diagonal block and next panel, T <- T - P P^T
+        for (int t = wave; t < nt; t += 4)
+            lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + r0, LD, S + (r0 + t * 16) * LD + c0, LD, S + r0 * LD + c0, LD, 16,
+                                 (T)-1, (T)1, lane);
         __syncthreads();
     }
 
     // L back to global (diagonal tiles of C above wrote the strictly upper 16x16 corners: mask them)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx >> 7, k = idx & 127;
-        A[(long)i * lda + k] = (k <= i) ? S[i * LD + k] : (T)0;
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+        if (k > i) v[0] = (T)0;
+        if (k + 1 > i) v[1] = (T)0;
+        *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
     }
     if (inv == nullptr) return;
     __syncthreads();
@@ -186,9 +205,9 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx >> 7, k = idx & 127;
-        inv[(long)i * ldi + k] = S[i * LD + k];
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = *reinterpret_cast<const pair_t*>(S + i * LD + k);
     }
 }
 

@@ -19,3 +19,9 @@ template <typename T>
 int pg_grbcm_finish_t(hipStream_t, int m, const double* sums, long lds, const T* mean_g, const T* var_g, T* mean, T* var,
                       double* beta0, double* prec0);
 template <typename T> int pg_tril_t(hipStream_t, int n, T* A, long lda);
+template <typename T>
+int pg_weighted_prec_t(hipStream_t, int m, int m_pad, const T* P, long ldp, const double* beta, T* acc, long lda, int accumulate);
+template <typename T> int pg_symmetrize_t(hipStream_t, int n, T* A, long lda);
+template <typename T>
+int pg_grbcm_finish_full_t(hipStream_t, int m, const double* sums, long lds, const T* mean_g, const T* var_g, const T* cov, long ldc,
+                           T* mean);

@@ -17,7 +17,11 @@
 #include <cstdlib>
 
 #define NB 128      // diagonal block / leaf size; inv_diag holds [n/128][128][128]
-#define NBO 1024    // outer panel of the Cholesky
+static int pg_nbo() {   // outer panel of the Cholesky (PG_NBO overrides, multiple of 128)
+    static int v = 0;
+    if (!v) { const char* e = getenv("PG_NBO"); v = e ? atoi(e) : 1024; if (v < 128 || v % 128) v = 1024; }
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // small kernels
@@ -219,6 +223,47 @@ __global__ __launch_bounds__(256) void grbcm_finish_kernel(const double* __restr
     mean[j] = (T)(v * (sums[2 * lds + j] + b0 * pg * (double)mean_g[j]));
 }
 
+// acc[i][j] (+)= 1/2 (beta_i + beta_j) P[i][j] on the lower triangle (gr_bcm.py:107-111); the padding keeps a unit diagonal
+template <typename T>
+__global__ __launch_bounds__(256) void weighted_prec_kernel(const T* __restrict__ P, long ldp, const double* __restrict__ beta,
+                                                            int m, int m_pad, T* __restrict__ acc, long lda, int accumulate) {
+    const int tc = blockIdx.x, tr = blockIdx.y;
+    if (tc > tr) return;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int i = tr * 64 + (idx >> 6), j = tc * 64 + (idx & 63);
+        if (i >= m_pad || j > i) continue;
+        T* a = acc + (long)i * lda + j;
+        if (i < m) {
+            const double v = 0.5 * (beta[i] + beta[j]) * (double)P[(long)i * ldp + j];
+            *a = (T)(accumulate ? (double)*a + v : v);
+        } else if (!accumulate) {
+            *a = (i == j) ? (T)1 : (T)0;
+        }
+    }
+}
+
+// A[i][j] = A[j][i] for j > i
+template <typename T> __global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, long lda, int n) {
+    const int tc = blockIdx.x, tr = blockIdx.y;
+    if (tc < tr) return;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int i = tr * 64 + (idx >> 6), j = tc * 64 + (idx & 63);
+        if (i < n && j < n && j > i) A[(long)i * lda + j] = A[(long)j * lda + i];
+    }
+}
+
+// mean[j] = cov[j][j] * (sum_c beta prec mu + beta_0 prec_0 mu_0)   (gr_bcm.py:147)
+template <typename T>
+__global__ __launch_bounds__(256) void grbcm_finish_full_kernel(const double* __restrict__ sums, long lds, const T* __restrict__ mean_g,
+                                                                const T* __restrict__ var_g, const T* __restrict__ cov, long ldc,
+                                                                int m, T* __restrict__ mean) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double pg = 1.0 / (double)var_g[j];
+    const double b0 = 1.0 - sums[j];
+    mean[j] = (T)((double)cov[(long)j * ldc + j] * (sums[2 * lds + j] + b0 * pg * (double)mean_g[j]));
+}
+
 #define LAUNCH_CHECK() PG_CHECK(hipGetLastError())
 
 // ------------------------------------------------------------------------------------------------
@@ -232,7 +277,7 @@ template <typename T> static GemmP<T> gp0() {
     p.alpha = (T)1; p.beta = (T)0;
     p.tri = p.klo = p.khi = 0;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
-    p.part = nullptr; p.ldp = 0; p.info = nullptr;
+    p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
     return p;
 }
 
@@ -262,6 +307,7 @@ template <typename T>
 int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
+    const int NBO = pg_nbo();
     const int npan = (n + NBO - 1) / NBO;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
     hipStream_t ps = la ? ctx->aux : st;   // panel stream
@@ -301,11 +347,11 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             }
             if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
             const int m = n - k0 - NB;
-            if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 128 full rows)
+            if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
                 GemmP<T> p = gp0<T>(); p.info = info;
                 p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
                 p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
-                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_128, p))) return rc;
+                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64x128, p))) return rc;
             }
         }
         if (la) {
@@ -482,6 +528,26 @@ int pg_grbcm_finish_t(hipStream_t st, int m, const double* sums, long lds, const
     LAUNCH_CHECK();
     return 0;
 }
+template <typename T>
+int pg_weighted_prec_t(hipStream_t st, int m, int m_pad, const T* P, long ldp, const double* beta, T* acc, long lda, int accumulate) {
+    const int t = (m_pad + 63) / 64;
+    hipLaunchKernelGGL(weighted_prec_kernel<T>, dim3(t, t), dim3(256), 0, st, P, ldp, beta, m, m_pad, acc, lda, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <typename T> int pg_symmetrize_t(hipStream_t st, int n, T* A, long lda) {
+    const int t = (n + 63) / 64;
+    hipLaunchKernelGGL(symmetrize_kernel<T>, dim3(t, t), dim3(256), 0, st, A, lda, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int pg_grbcm_finish_full_t(hipStream_t st, int m, const double* sums, long lds, const T* mean_g, const T* var_g, const T* cov,
+                           long ldc, T* mean) {
+    hipLaunchKernelGGL(grbcm_finish_full_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, sums, lds, mean_g, var_g, cov, ldc, m, mean);
+    LAUNCH_CHECK();
+    return 0;
+}
 template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     const int t = (n + 63) / 64;
     hipLaunchKernelGGL(tril_kernel<T>, dim3(t, t), dim3(256), 0, st, A, lda, n);
@@ -504,6 +570,10 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
                                      double*);                                                                         \
     template int pg_grbcm_finish_t<T>(hipStream_t, int, const double*, long, const T*, const T*, T*, T*, double*,     \
                                       double*);                                                                        \
+    template int pg_weighted_prec_t<T>(hipStream_t, int, int, const T*, long, const double*, T*, long, int);            \
+    template int pg_symmetrize_t<T>(hipStream_t, int, T*, long);                                                       \
+    template int pg_grbcm_finish_full_t<T>(hipStream_t, int, const double*, long, const T*, const T*, const T*, long,  \
+                                           T*);                                                                        \
     template int pg_tril_t<T>(hipStream_t, int, T*, long);
 INST(double)
 INST(float)

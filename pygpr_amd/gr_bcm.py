@@ -18,8 +18,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._ops import get_ops
-from .gpr import GPR, Exact_GP
+from ._ops import get_ops, pad_to
+from .gpr import GPR, Exact_GP, _lin_alg_error
 from .loss import MLE, Loss
 
 
@@ -100,35 +100,95 @@ class GRBCM(GPR):
             _all_reduce_sum(sums, self.group)
         mean, var = ops.empty(m, dtype=mean_g.dtype), ops.empty(m, dtype=mean_g.dtype)
         ops.grbcm_finish(sums, mean_g, var_g, mean, var, beta[0], prec[0])
-        self.beta, self.prec = beta, prec
+        self.beta, self.prec, self._sums = beta, prec, sums
         return mean, var
+
+    def _padded_spd(self, cov):
+        """m x m covariance -> padded device copy with a unit diagonal in the padding."""
+        ops = get_ops()
+        m = cov.shape[0]
+        mp = pad_to(m)
+        a = ops.zeros(mp, mp, dtype=cov.dtype)
+        a[:m, :m] = cov
+        if mp > m:
+            a.diagonal()[m:] = 1.0
+        return a
+
+    def _aggregate_full_device(self, mean_g, cov_g, means_l, covs_l):
+        """aggregate(var="full") + aggregate_full_covar (gr_bcm.py:99-114,138-147) on device tensors: the weights come
+        from the diagonal variances exactly as in the diag case; every expert's m x m covariance is inverted with the
+        blocked Cholesky / L^-1 / L^-T L^-1 kernels, combined with 1/2 (beta_i + beta_j), and inverted back.  Multi-GPU:
+        one extra all-reduce of the [m_pad, m_pad] weighted precision."""
+        ops = get_ops()
+        m = mean_g.numel()
+        var_g = cov_g.diagonal().contiguous()
+        vars_l = [c.diagonal().contiguous() for c in covs_l]
+        self._aggregate_device(mean_g, var_g, means_l, vars_l)       # fills self._sums, beta, prec
+        acc = None
+        infos = []
+        for c, cov in enumerate(covs_l):
+            pc, info = ops.spd_inverse_lower(self._padded_spd(cov))
+            infos.append(info)
+            if acc is None:
+                acc = ops.empty(pc.shape[0], pc.shape[0], dtype=pc.dtype)
+            ops.grbcm_weighted_prec(pc, self.beta[c + 1].contiguous(), acc, m, c > 0)
+        if acc is None:
+            acc = self._padded_spd(torch.zeros(m, m, dtype=cov_g.dtype, device=cov_g.device))
+            acc.diagonal()[:m] = 0.0
+        if self.distributed:
+            mp = acc.shape[0]
+            if mp > m and self.world > 1:          # keep the padding's unit diagonal a unit after the sum
+                acc.diagonal()[m:] = 1.0 / self.world
+            _all_reduce_sum(acc, self.group)
+        p0, info = ops.spd_inverse_lower(self._padded_spd(cov_g))
+        infos.append(info)
+        ops.grbcm_weighted_prec(p0, self.beta[0].contiguous(), acc, m, True)
+        cov, info = ops.spd_inverse_lower(acc)
+        infos.append(info)
+        for i in infos:
+            k = int(i.item())
+            if k:
+                raise _lin_alg_error(k)
+        ops.symmetrize(cov, cov.shape[0])
+        mean = ops.empty(m, dtype=mean_g.dtype)
+        ops.grbcm_finish_full(self._sums, mean_g, var_g, cov, mean)
+        return mean, cov[:m, :m]
 
     def aggregate(self, ys_g, covars_g, ys_l, covars_l, var="diag"):
         """GRBCM.aggregate (gr_bcm.py:116-149) on tensors shaped like Exact_GP.predict's outputs."""
-        if var != "diag":
-            raise NotImplementedError("full-covariance aggregation (gr_bcm.py:99-114) is not on the device path yet")
         ops = get_ops()
         dt = ys_g.dtype
-        mg, vg = ops.to_device(ys_g.reshape(-1), dt), ops.to_device(covars_g.reshape(-1), dt)
-        ml = ops.to_device(ys_l.reshape(-1, mg.numel()), dt)
-        vl = ops.to_device(covars_l.reshape(-1, mg.numel()), dt)
-        mean, var_ = self._aggregate_device(mg, vg, list(ml), list(vl))
+        m = ys_g.numel()
+        mg = ops.to_device(ys_g.reshape(-1), dt)
+        ml = list(ops.to_device(ys_l.reshape(-1, m), dt))
+        if var == "diag":
+            vg = ops.to_device(covars_g.reshape(-1), dt)
+            vl = list(ops.to_device(covars_l.reshape(-1, m), dt))
+            mean, out = self._aggregate_device(mg, vg, ml, vl)
+        else:
+            cg = ops.to_device(covars_g.reshape(m, m), dt)
+            cl = list(ops.to_device(covars_l.reshape(-1, m, m), dt))
+            mean, out = self._aggregate_full_device(mg, cg, ml, cl)
+            out = out.contiguous()
         self.beta, self.prec = self.beta.to(ys_g.device), self.prec.to(ys_g.device)
-        return mean.to(ys_g.device), var_.to(ys_g.device)
+        return mean.to(ys_g.device), out.to(ys_g.device)
 
     def predict(self, xs, var="diag"):
-        if var != "diag":
-            raise NotImplementedError("GRBCM.predict(var='full') (gr_bcm.py:99-114) is not on the device path yet")
         ops = get_ops()
+        want = "diag" if var == "diag" else "full"
         xsd = ops.to_device(xs.reshape(-1, xs.shape[-1]), self.gpg.dtype)
-        mg, vg = self.gpg._predict_device(xsd, "diag")
+        mg, vg = self.gpg._predict_device(xsd, want)
         if self.gpl is not None:
-            ml, vl = self.gpl._predict_device(xsd, "diag")
+            ml, vl = self.gpl._predict_device(xsd, want)
         else:
             ml, vl = [], []
-        mean, var_ = self._aggregate_device(mg[0], vg[0], ml, vl)
+        if want == "diag":
+            mean, out = self._aggregate_device(mg[0], vg[0], ml, vl)
+        else:
+            mean, out = self._aggregate_full_device(mg[0], vg[0], ml, vl)
+            out = out.contiguous()
         self.beta, self.prec = self.beta.to(xs.device), self.prec.to(xs.device)
-        return mean.to(xs.device), var_.to(xs.device)
+        return mean.to(xs.device), out.to(xs.device)
 
 
 class GRBCM_MLE(Loss):

@@ -169,3 +169,30 @@ class OracleOps:
             beta0.copy_(1.0 - sums[0])
         if prec0 is not None:
             prec0.copy_(torch.from_numpy(1.0 / _np(var_g).astype(np.float64)))
+
+    # full-covariance committee
+    def grbcm_weighted_prec(self, prec, beta, acc, m, accumulate):
+        p, b, a = _np(prec).astype(np.float64), _np(beta), _np(acc)
+        w = np.tril(0.5 * (b[:, None] + b[None, :]) * p[:m, :m])
+        if not accumulate:
+            a[...] = np.eye(a.shape[0])
+            a[:m, :m] = 0.0
+        a[:m, :m] += w
+
+    def symmetrize(self, a, n):
+        low = np.tril(_np(a)[:n, :n])
+        _np(a)[:n, :n] = low + np.tril(low, -1).T
+
+    def grbcm_finish_full(self, sums, mean_g, var_g, cov, mean):
+        s = _np(sums)
+        pg_ = 1.0 / _np(var_g).astype(np.float64)
+        mean.copy_(torch.from_numpy(np.diag(_np(cov))[: s.shape[1]] * (s[2] + (1.0 - s[0]) * pg_ * _np(mean_g).astype(np.float64))))
+
+    def spd_inverse_lower(self, a_pad):
+        info = torch.zeros(1, dtype=torch.int32)
+        self.potrf(a_pad, None, info)
+        minv = torch.zeros_like(a_pad)
+        self.trtri(a_pad, None, minv)
+        out = torch.zeros_like(a_pad)
+        self.lauum(minv, out)
+        return out, info

@@ -110,8 +110,11 @@ def test_grbcm_and_drivers_on_host(fake_ops, golden):
     np.testing.assert_allclose(mu.numpy(), g[p + "mu"], atol=1e-10)
     np.testing.assert_allclose(var.numpy(), g[p + "var"], atol=1e-11)
     np.testing.assert_allclose(m.beta.numpy(), g[p + "beta"], atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        m.predict(T(g[p + "xs"]), var="full")
+    if int(g[p + "full_ok"]):
+        m.gpl.set_params(T(np.broadcast_to(g[p + "hpg"], g[p + "hpl"].shape).copy()))
+        mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
+        np.testing.assert_allclose(cov_f.numpy(), g[p + "cov_full"], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(mu_f.numpy(), g[p + "mu_full"], rtol=1e-6, atol=1e-9)
     gg = golden("gp")
     gpd = pg.Exact_GP(T(gg["d_x"]), T(gg["d_y"]), se_wn())
     gpd.set_params(T(gg["d_hp"]))

@@ -288,6 +288,12 @@ def test_grbcm_golden(golden):
         np.testing.assert_allclose(N(m.beta), g[p + "beta"], atol=1e-9)
         np.testing.assert_allclose(N(m.prec), g[p + "prec"], rtol=1e-9)
         assert (m.nc, m.nsc, m.ng, m.dim) == (g[p + "xl"].shape[0], 50, 20, 3)
+        if int(g[p + "full_ok"]):   # full-covariance committee (gr_bcm.py:99-114), shared hp as in the fixture
+            m.gpl.set_params(T(np.broadcast_to(g[p + "hpg"], g[p + "hpl"].shape).copy()))
+            mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
+            np.testing.assert_allclose(N(cov_f), g[p + "cov_full"], rtol=1e-6, atol=1e-10)
+            np.testing.assert_allclose(N(mu_f), g[p + "mu_full"], rtol=1e-6, atol=1e-9)
+            assert torch.equal(cov_f, cov_f.T)
 
 
 @pytest.mark.parametrize("ng,nc,n,d", [(10, 2, 10, 2), (100, 5, 50, 3), (100, 10, 100, 7)])

@@ -1,0 +1,21 @@
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from pygpr_amd._ops import get_ops, make_spec
+ops = get_ops()
+for n in (8192, 16384):
+    d = 8
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy(rng.random((n, d))).cuda()
+    hp = torch.tensor([1.0] + [1.0] * d + [0.1], dtype=torch.float64).cuda()
+    spec = make_spec([0], [0], [d + 1])
+    kl = ops.empty(n, n)
+    invd = ops.potrf_workspace(n, torch.float64); info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    def run():
+        ops.kernel_build(spec, hp, x, None, kl, lower_only=True, jitter=1e-7); ops.potrf(kl, invd, info)
+    for la in (1, 0):
+        ops.set_lookahead(la)
+        run(); torch.cuda.synchronize(); best = 1e9
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); run(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
+        print(f"n={n} lookahead={la} build+potrf {best:.2f} ms -> potrf ~{n**3/3/(best-0.45*(n/16384)**2)/1e9:.1f} TF/s info={int(info.item())}", flush=True)
