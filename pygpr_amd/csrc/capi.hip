@@ -70,8 +70,11 @@ int pg_create(pg_handle* h) {
         const int words = (ncu + 31) / 32;
         uint32_t mask[64];
         for (int i = 0; i < 64; ++i) mask[i] = 0;
-        for (int cu = 0; cu < ncu - PG_RESERVED_CUS; ++cu) mask[cu / 32] |= (1u << (cu % 32));
-        if (ncu <= PG_RESERVED_CUS * 4 || words > 64 ||
+        const char* env = getenv("PG_RESERVED_CUS");
+        int reserved = env ? atoi(env) : PG_RESERVED_CUS;
+        if (reserved < 1 || reserved > ncu / 2) reserved = PG_RESERVED_CUS;
+        for (int cu = 0; cu < ncu - reserved; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+        if (ncu <= reserved * 2 || words > 64 ||
             hipExtStreamCreateWithCUMask(&c->upd, (uint32_t)words, mask) != hipSuccess) {
             c->upd = nullptr;
             c->lookahead = 0;

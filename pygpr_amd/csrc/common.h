@@ -6,7 +6,7 @@
 #include "pygpr_hip.h"
 
 #define PG_TILE 128      // GEMM block tile and Cholesky leaf size
-#define PG_RESERVED_CUS 8
+#define PG_RESERVED_CUS 32   // default; PG_RESERVED_CUS in the environment overrides
 #define PG_PAD 256       // every matrix dimension handed to the O(n^3) kernels is a multiple of this
 
 

@@ -112,15 +112,14 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
                 const T rs = ok ? inv_sqrt(piv) : (T)0;
                 const T lrc = row[c] * rs;           // lane c: sqrt(piv); lanes r < c: 0 (upper part is zero)
                 row[c] = lrc;
-                const T mult = (r > c) ? lrc : (T)0;
 #pragma unroll
                 for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
-                // row c of X is complete once scaled by 1/l_cc; rows below eliminate it
+                // row c of X is complete once scaled by 1/l_cc (xc); rows below eliminate it: x_r -= l_rc xc.
+                // Lane c itself must end up with xc = x_c rs: x_c - (l_cc - 1) xc = x_c rs (l_cc rs = 1), so one masked
+                // multiplier serves all three cases and the loop is a plain broadcast + fma.
+                const T mult = (r > c) ? lrc : ((r == c) ? lrc - (T)1 : (T)0);
 #pragma unroll
-                for (int j = 0; j <= c; ++j) {
-                    const T xc = bcast_lane(xr[j], c) * rs;
-                    xr[j] = (r == c) ? xc : xr[j] - mult * xc;
-                }
+                for (int j = 0; j <= c; ++j) xr[j] -= mult * (bcast_lane(xr[j], c) * rs);
             }
             if (lane < 16) {
                 T* Dv = Dinv + jb * 16 * DLD;

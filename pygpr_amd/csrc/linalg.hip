@@ -298,11 +298,12 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
 
 // Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
 // panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
-//   panel stream (handle's high-priority stream):  Chain(0) Sa(0) Chain(1) [wait Sb(0)] Sa(1) Chain(2) ...
-//   update stream (handle's CU-masked stream)   :           [wait Chain(0)] Sb(0) [wait Chain(1)] Sb(1) ...
-// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap; Sa(o) and
-// Sb(o-1) both read-modify-write panel o+1's columns, hence the wait.  Everything is joined back onto the caller's
-// stream at the end.
+//   panel stream  (handle's high-priority stream)       : Chain(0)            [wait Sa(0)] Chain(1)        [wait Sa(1)] Chain(2) ...
+//   update stream (handle's CU-masked stream)            :   [wait Chain(0)] Sa(0) Sb(0)     [wait Chain(1)] Sa(1) Sb(1) ...
+// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap.  The update
+// stream may not use the last PG_RESERVED_CUS compute units: the chain's small kernels (and the leaf, which needs a
+// whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
+// the caller's stream at the end.
 template <typename T>
 int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
@@ -311,7 +312,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     const int npan = (n + NBO - 1) / NBO;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
     hipStream_t ps = la ? ctx->aux : st;   // panel stream
-    hipStream_t us = la ? ctx->upd : st;   // update stream (CU-masked so the leaf always finds a free CU)
+    hipStream_t us = la ? ctx->upd : st;   // update stream
     hipEvent_t ev;
     int rc;
     if (la) {
@@ -320,20 +321,11 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
         PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
         PG_CHECK(hipStreamWaitEvent(us, ev, 0));
     }
-    int last_sb = -1;
     for (int o = 0; o < npan; ++o) {
         const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
-        if (o > 0) {   // Sa(o-1): this panel's columns -= previous panel
-            if (la && o >= 2) {
-                if ((rc = pool_event(ctx, 2 + 2 * (o - 2) + 1, &ev))) return rc;   // ev_sb[o-2]
-                PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
-            }
-            const int p0 = o0 - NBO;
-            GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = n - o0; p.N = oend - o0; p.K = NBO;
-            p.A = A + (long)o0 * lda + p0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o0 * lda + o0; p.ldc = lda;
-            p.alpha = (T)-1; p.beta = (T)1;
-            if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_128, p))) return rc;
+        if (la && o > 0) {   // this panel's columns must have received Sa(o-1)
+            if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
+            PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
         }
         for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
             T* Akk = A + (long)k0 * lda + k0;
@@ -354,35 +346,44 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64x128, p))) return rc;
             }
         }
+        if (oend >= n) break;
         if (la) {
             if ((rc = pool_event(ctx, 2 + 2 * o, &ev))) return rc;       // ev_chain[o]
             PG_CHECK(hipEventRecord(ev, ps));
+            PG_CHECK(hipStreamWaitEvent(us, ev, 0));
         }
         const int o2 = std::min(n, oend + NBO);   // first column right of panel o+1
+        {   // Sa(o): panel o+1's columns -= panel o
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
+            p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1;
+            // few 128x128 tiles with a 1024-deep K loop leave most CUs idle: use 64x64 tiles then (4x the workgroups)
+            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+        }
+        if (la) {
+            if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sa[o]
+            PG_CHECK(hipEventRecord(ev, us));
+        }
         const int m2 = n - o2;
         if (m2 > 0) {  // Sb(o)
-            if (la) PG_CHECK(hipStreamWaitEvent(us, ev, 0));
             T* P = A + (long)o2 * lda + o0;
             GemmP<T> p = gp0<T>(); p.info = info;
             p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
             p.C = A + (long)o2 * lda + o2; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
-            if ((rc = pg_gemm<T>(ctx, us, GEMM_NT_128, p))) return rc;
-            if (la) {
-                if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]
-                PG_CHECK(hipEventRecord(ev, us));
-                last_sb = o;
-            }
+            const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
     }
-    if (la) {
+    if (la) {   // join both streams back onto the caller's stream
         if ((rc = pool_event(ctx, 1, &ev))) return rc;
         PG_CHECK(hipEventRecord(ev, ps));
         PG_CHECK(hipStreamWaitEvent(st, ev, 0));
-        if (last_sb >= 0) {
-            if ((rc = pool_event(ctx, 2 + 2 * last_sb + 1, &ev))) return rc;
-            PG_CHECK(hipStreamWaitEvent(st, ev, 0));
-        }
+        if ((rc = pool_event(ctx, 2 + 2 * npan, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, us));
+        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
     }
     return 0;
 }
