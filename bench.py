@@ -12,7 +12,7 @@ Extra objects on the same JSON line:
   roofline      the MFMA GEMM core (all instantiations of pg_gemm_kernel) over one evaluation: algorithmic
                 flop of its launches / summed launch durations measured with HIP events inside the library
                 (pg_profile), against the fp64 matrix peak; plus potrf alone and the covariance build (HBM)
-  cpu_baseline  the CPU oracle's lean K^-1-route evaluation (oracle/pygpr_oracle.py, LAPACK via SciPy) timed
+  cpu_baseline  the CPU oracle's lean K^-1-route evaluation (oracle/pygpr_oracle.py, torch CPU + LAPACK) timed
                 on this host's cores at a bounded size and n^3-scaled to N = 16384
   grbcm_predict BASELINE config 4 (8 experts x (1024 + 8192) points, D = 16, 65536 test points): committee
                 predictions/sec, experts sharded over the ranks, one [3, m] all-reduce per test batch
