@@ -132,6 +132,11 @@ int pg_symmetrize(pg_handle h, int dtype, int n, void* A, long lda, void* stream
 int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
                          const void* cov, long ldc, void* mean, void* stream);
 
+/* Expert partitioning (sampler.py:68-119).  D[i][j] = |x_i - c_j|^2 (euclidean_dist, sampler.py:94-100; D may be NULL)
+ * and idx[i] = argmin_j, first minimum (the assignment of cluster_samples, sampler.py:80-82,112-116; idx may be NULL). */
+int pg_sqdist_argmin(pg_handle h, int dtype, const void* X, long ldx, int n, const void* C, long ldc, int m, int d, void* D,
+                     long ldd, int* idx, void* stream);
+
 /* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
 

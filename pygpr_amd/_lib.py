@@ -54,6 +54,7 @@ _SIGS = {
     "pg_grbcm_weighted_prec": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _i, _vp]),
     "pg_symmetrize": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_grbcm_finish_full": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp]),
+    "pg_sqdist_argmin": (_i, [_vp, _i, _vp, _l, _i, _vp, _l, _i, _i, _vp, _l, _vp, _vp]),
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_set_lookahead": (_i, [_vp, _i]),
     "pg_profile": (_i, [_vp, _i]),

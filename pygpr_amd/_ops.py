@@ -201,6 +201,13 @@ class HipOps:
         self.lauum(minv, out)
         return out, info
 
+    def sqdist_argmin(self, x, centres, dist=None, idx=None):
+        """dist[n, m] = squared distances, idx[n] (int32) = nearest centre; either output may be None."""
+        self._chk(x, centres, dist, idx)
+        _lib.check(self.lib.pg_sqdist_argmin(self.h, _code(x.dtype), _p(x), x.stride(0), x.shape[0], _p(centres),
+                                             centres.stride(0), centres.shape[0], x.shape[1], _p(dist),
+                                             dist.stride(0) if dist is not None else 0, _p(idx), self._st()), "pg_sqdist_argmin")
+
     # -- raw GEMM core (tests, roofline micro-benchmark) ---------------------------------------
     def gemm_raw(self, variant, m, n, k, alpha, a, b, beta, c, tri=0, klo=0, khi=0):
         self._chk(a, b, c)

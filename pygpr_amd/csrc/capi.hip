@@ -275,6 +275,14 @@ int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long
                                            ldc, (float*)mean));
 }
 
+int pg_sqdist_argmin(pg_handle h, int dtype, const void* X, long ldx, int n, const void* C, long ldc, int m, int d, void* D,
+                     long ldd, int* idx, void* stream) {
+    NEED(h && X && C && (D || idx), "null pointer");
+    DISPATCH(dtype,
+             pg_centres<double>(ST(stream), (const double*)X, ldx, n, (const double*)C, ldc, m, d, (double*)D, ldd, idx),
+             pg_centres<float>(ST(stream), (const float*)X, ldx, n, (const float*)C, ldc, m, d, (float*)D, ldd, idx));
+}
+
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
     NEED(h && A, "null pointer");
     DISPATCH(dtype, pg_tril_t<double>(ST(stream), n, (double*)A, lda), pg_tril_t<float>(ST(stream), n, (float*)A, lda));

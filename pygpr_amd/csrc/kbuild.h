@@ -11,4 +11,6 @@ int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, con
                    const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork);
 long pg_nlml_grad_worksize_impl(int n, int nhp);
 template <typename T>
+int pg_centres(hipStream_t st, const T* X, long ldx, int n, const T* Cn, long ldc, int m, int d, T* D, long ldd, int* idx);
+template <typename T>
 int pg_kgrad(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, T* dK);

@@ -244,6 +244,51 @@ template int pg_kgrad<double>(hipStream_t, const pg_covspec&, const double*, con
 template int pg_kgrad<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int, int, float*);
 
 // ------------------------------------------------------------------------------------------------
+// expert partitioning (sampler.py:68-119): squared distances to a small set of centres and the nearest centre.
+// One thread per point, centres staged in LDS; direct differences (the reference expands into a GEMM, sampler.py:94-100).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pg_centres_kernel(const T* __restrict__ X, long ldx, int n, const T* __restrict__ Cn,
+                                                         long ldc, int m, int d, T* __restrict__ D, long ldd,
+                                                         int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* cs = reinterpret_cast<T*>(smem_raw);          // [chunk][d]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = min(m, 1024);
+    T best = (T)0;
+    int arg = 0;
+    for (int j0 = 0; j0 < m; j0 += chunk) {
+        const int mc = min(chunk, m - j0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < mc * d; e += 256) cs[e] = Cn[(long)(j0 + e / d) * ldc + e % d];
+        __syncthreads();
+        if (i < n) {
+            for (int j = 0; j < mc; ++j) {
+                T s = (T)0;
+                for (int k = 0; k < d; ++k) {
+                    const T df = X[(long)i * ldx + k] - cs[j * d + k];
+                    s += df * df;
+                }
+                if (D) D[(long)i * ldd + j0 + j] = s;
+                if ((j0 + j == 0) || s < best) { best = s; arg = j0 + j; }
+            }
+        }
+    }
+    if (idx && i < n) idx[i] = arg;
+}
+
+template <typename T>
+int pg_centres(hipStream_t st, const T* X, long ldx, int n, const T* Cn, long ldc, int m, int d, T* D, long ldd, int* idx) {
+    if (n <= 0 || m <= 0 || d < 1 || d > PG_MAX_DIM) { pg_set_error("pg_sqdist: bad shape n=%d m=%d d=%d", n, m, d); return -2; }
+    const size_t lds = (size_t)std::min(m, 1024) * d * sizeof(T);
+    hipLaunchKernelGGL(pg_centres_kernel<T>, dim3((n + 255) / 256), dim3(256), lds, st, X, ldx, n, Cn, ldc, m, d, D, ldd, idx);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+template int pg_centres<double>(hipStream_t, const double*, long, int, const double*, long, int, int, double*, long, int*);
+template int pg_centres<float>(hipStream_t, const float*, long, int, const float*, long, int, int, float*, long, int*);
+
+// ------------------------------------------------------------------------------------------------
 // fused gradient contraction
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DMAX>

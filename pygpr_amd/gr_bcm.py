@@ -75,6 +75,21 @@ class GRBCM(GPR):
         self.beta = NotImplemented
         self.prec = NotImplemented
 
+    # ---- shared hyper-parameters: lets Opt/CG/get_learn_rate drive a GRBCM through GRBCM_MLE -------------------
+    @property
+    def params(self):
+        """The global expert's hyper-parameters (the shared vector when the committee is co-trained)."""
+        return self.gpg.params
+
+    def set_params(self, params):
+        """One hyper-parameter vector for the global and every local expert (shared-hp co-training)."""
+        self.gpg.set_params(params)
+        self.set_local_params(params)
+
+    @property
+    def need_upd(self):
+        return self.gpg.need_upd or (self.gpl is not None and self.gpl.need_upd)
+
     def set_local_params(self, params_all):
         """params_all [nc, nhp] (or [nhp], shared): keep this rank's rows."""
         if self.gpl is None:

@@ -204,7 +204,28 @@ def grbcm_cases():
     print("grbcm cases", idx)
 
 
+# ---- samplers / partitioning (sampler.py) ------------------------------------
+def sampler_cases():
+    out = {}
+    mins, maxs = tc.tensor([0.0, -1.0]), tc.tensor([2.0, 1.0])
+    out["mins"], out["maxs"] = N(mins), N(maxs)
+    out["uni"] = N(ref.UNIFORM(3).sample(50, mins, maxs))
+    m1 = ref.MATERN1(5)
+    out["mat"] = N(m1.sample(12, mins, maxs))
+    out["mat_min_dist"] = np.array(float(m1.min_dist))
+    xpart, xc = ref.MATERN1(7).partition(4, 25, mins, maxs)
+    out["part_x"], out["part_xc"] = N(xpart), N(xc)
+    x = tc.rand(40, 3)
+    y = tc.rand(6, 3)
+    out["ed_x"], out["ed_y"], out["ed"] = N(x), N(y), N(ref.euclidean_dist(x, y))
+    flat = xpart.reshape(-1, 2)[tc.randperm(100)]
+    out["cs_x"], out["cs"] = N(flat), N(ref.cluster_samples(flat, xc))
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+    print("sampler cases done")
+
+
 if __name__ == "__main__":
     covar_cases()
     gp_cases()
     grbcm_cases()
+    sampler_cases()

@@ -196,3 +196,11 @@ class OracleOps:
         out = torch.zeros_like(a_pad)
         self.lauum(minv, out)
         return out, info
+
+    def sqdist_argmin(self, x, centres, dist=None, idx=None):
+        xx, cc = _np(x).astype(np.float64), _np(centres).astype(np.float64)
+        d2 = ((xx[:, None, :] - cc[None, :, :]) ** 2).sum(2)
+        if dist is not None:
+            dist.copy_(torch.from_numpy(d2))
+        if idx is not None:
+            idx.copy_(torch.from_numpy(np.argmin(d2, axis=1).astype(np.int32)))

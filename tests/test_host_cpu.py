@@ -115,6 +115,13 @@ def test_grbcm_and_drivers_on_host(fake_ops, golden):
         mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
         np.testing.assert_allclose(cov_f.numpy(), g[p + "cov_full"], rtol=1e-6, atol=1e-10)
         np.testing.assert_allclose(mu_f.numpy(), g[p + "mu_full"], rtol=1e-6, atol=1e-9)
+    m.set_params(T(np.array([1.0, 1.0, 1.0, 1.0, 0.2])))      # shared-hp training through the stock CG driver (8f-2)
+    gl = pg.GRBCM_MLE(m)
+    f0 = float(gl.loss(m.params.numpy()))
+    cgm = pg.CG(gl)
+    cgm.args.update(maxiter=3, disp=False)
+    cgm.minimize()
+    assert float(cgm.res.fun) < f0 and torch.equal(m.gpl.params[0], m.gpg.params)
     gg = golden("gp")
     gpd = pg.Exact_GP(T(gg["d_x"]), T(gg["d_y"]), se_wn())
     gpd.set_params(T(gg["d_hp"]))
@@ -149,3 +156,23 @@ def test_quadratic_optimisers_mock_loss(tmp_path, monkeypatch):
         pg.Loss(None).loss(np.zeros(2))
     with pytest.raises(NotImplementedError):
         pg.GPR(None, None, None).update()
+
+
+def _check_sampler(golden):
+    g = golden("sampler")
+    mins, maxs = T(g["mins"]), T(g["maxs"])
+    assert torch.equal(pg.UNIFORM(3).sample(50, mins, maxs), T(g["uni"]))          # same generator call sequence
+    m1 = pg.MATERN1(5)
+    assert torch.equal(m1.sample(12, mins, maxs), T(g["mat"]))
+    np.testing.assert_allclose(float(m1.min_dist), g["mat_min_dist"], rtol=1e-14)
+    xpart, xc = pg.MATERN1(7).partition(4, 25, mins, maxs)
+    assert torch.equal(xc, T(g["part_xc"])) and torch.equal(xpart, T(g["part_x"]))
+    np.testing.assert_allclose(pg.euclidean_dist(T(g["ed_x"]), T(g["ed_y"])).numpy(), g["ed"], atol=1e-14)
+    assert torch.equal(pg.cluster_samples(T(g["cs_x"]), T(g["part_xc"])), T(g["cs"]))
+    # the shards feed GRBCM directly (this is what the reference's test_grbcm.py does with MATERN1.partition)
+    m = pg.GRBCM(xpart, torch.sin(xpart.sum(-1)), xc, torch.sin(xc.sum(-1)), pg.Compose([pg.Squared_exponential(), pg.White_noise()]))
+    assert (m.nc, m.nsc, m.ng, m.dim) == (4, 25, 4, 2)
+
+
+def test_samplers_and_partition_host(fake_ops, golden):
+    _check_sampler(golden)

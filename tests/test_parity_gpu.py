@@ -320,6 +320,28 @@ def test_grbcm_shared_hp_objective_matches_summed_oracle(golden):
     np.testing.assert_allclose(grad, gref, rtol=1e-8, atol=1e-8 * np.abs(gref).max())
 
 
+def test_grbcm_shared_hp_training_with_cg(golden):
+    """the dead GRBCM.train is replaced by GRBCM_MLE + the stock CG driver (opt.py:45-67)."""
+    g = golden("grbcm")
+    p = "g0_"
+    m = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), se_wn())
+    m.set_params(T(np.array([1.0, 1.0, 1.0, 1.0, 0.2])))
+    loss = pg.GRBCM_MLE(m)
+    f0 = float(loss.loss(N(m.params)))
+    cg = pg.CG(loss)
+    cg.args.update(maxiter=4, disp=False)
+    cg.minimize()
+    assert float(cg.res.fun) < f0 - 1.0                       # it descends
+    assert torch.equal(m.gpg.params, torch.from_numpy(cg.res.x)) and m.gpl.params.shape == (2, 5)
+    assert torch.equal(m.gpl.params[1], m.gpg.params) and m.need_upd
+    mu, var = m.predict(T(g[p + "xs"]), var="diag")           # and the retrained committee predicts
+    assert torch.isfinite(mu).all() and (var > 0).all()
+    # same objective value as the oracle at the optimum found
+    x, y = orc.grbcm_data(g[p + "xl"], g[p + "yl"], g[p + "xg"], g[p + "yg"])
+    ref = sum(orc.mle_loss(( [orc.SE, orc.WN] ), cg.res.x, x[c], y[c]) for c in range(x.shape[0]))
+    np.testing.assert_allclose(float(loss.loss(cg.res.x)), ref, rtol=1e-9)
+
+
 # ------------------------------------------------------------------ fp32 opt-in and full-size properties
 def test_fp32_opt_in():
     n, d = 600, 8
@@ -359,3 +381,30 @@ def test_cfg2_size_properties():
     mu, _ = gp.predict(T(x[:2048]), var="none")
     alpha = N(gp.wt)
     np.testing.assert_allclose(N(mu), y[:2048] - (hp[-1] ** 2 + 1e-7) * alpha[:2048], atol=1e-8)
+
+
+def _check_sampler(golden):
+    g = golden("sampler")
+    mins, maxs = T(g["mins"]), T(g["maxs"])
+    assert torch.equal(pg.UNIFORM(3).sample(50, mins, maxs), T(g["uni"]))          # same generator call sequence
+    m1 = pg.MATERN1(5)
+    assert torch.equal(m1.sample(12, mins, maxs), T(g["mat"]))
+    np.testing.assert_allclose(float(m1.min_dist), g["mat_min_dist"], rtol=1e-14)
+    xpart, xc = pg.MATERN1(7).partition(4, 25, mins, maxs)
+    assert torch.equal(xc, T(g["part_xc"])) and torch.equal(xpart, T(g["part_x"]))
+    np.testing.assert_allclose(pg.euclidean_dist(T(g["ed_x"]), T(g["ed_y"])).numpy(), g["ed"], atol=1e-14)
+    assert torch.equal(pg.cluster_samples(T(g["cs_x"]), T(g["part_xc"])), T(g["cs"]))
+    # the shards feed GRBCM directly (this is what the reference's test_grbcm.py does with MATERN1.partition)
+    m = pg.GRBCM(xpart, torch.sin(xpart.sum(-1)), xc, torch.sin(xc.sum(-1)), pg.Compose([pg.Squared_exponential(), pg.White_noise()]))
+    assert (m.nc, m.nsc, m.ng, m.dim) == (4, 25, 4, 2)
+
+
+def test_samplers_and_partition(golden):
+    """the nearest-centre assignment / distance matrix of sampler.py on the device."""
+    _check_sampler(golden)
+    rng = np.random.default_rng(0)
+    x, c = rng.random((5000, 7)), rng.random((300, 7))
+    from pygpr_amd.sampler import nearest_centre
+    d2 = ((x[:, None, :] - c[None, :, :]) ** 2).sum(2)
+    assert np.array_equal(N(nearest_centre(T(x), T(c))), np.argmin(d2, axis=1))
+    np.testing.assert_allclose(N(pg.euclidean_dist(T(x), T(c))), d2, atol=1e-13)
