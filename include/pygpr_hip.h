@@ -68,6 +68,13 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
 
+/* pg_potrf followed by pg_trtri in one call: Minv = L^-1 as well (tc.cholesky + the triangular half of the
+ * cholesky_solve calls of loss.py:97,116).  The inverse of the leading half of L and the product L21 Minv11 of the
+ * top level only need columns that are final half-way through the factorisation; they run on a background stream
+ * while the chain-bound tail of the Cholesky leaves most of the chip idle. */
+int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
+                   void* stream);
+
 /* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
  * work: 2 n elements. */
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,

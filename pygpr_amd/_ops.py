@@ -100,6 +100,12 @@ class HipOps:
         _lib.check(self.lib.pg_potrf(self.h, _code(a.dtype), a.shape[0], _p(a), a.stride(0), _p(invd), _p(info),
                                      self._st()), "pg_potrf")
 
+    def potrf_trtri(self, a, invd, info, minv):
+        """Cholesky in place + minv = L^-1, fused so that part of the inverse overlaps the factorisation's tail."""
+        self._chk(a, invd, info, minv)
+        _lib.check(self.lib.pg_potrf_trtri(self.h, _code(a.dtype), a.shape[0], _p(a), a.stride(0), _p(invd), _p(info),
+                                           _p(minv), minv.stride(0), self._st()), "pg_potrf_trtri")
+
     def potrs_vec(self, chol, invd, y, x, work=None):
         if work is None:
             work = self.empty(2 * chol.shape[0], dtype=chol.dtype)

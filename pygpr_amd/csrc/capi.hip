@@ -80,6 +80,16 @@ int pg_create(pg_handle* h) {
             c->lookahead = 0;
             (void)hipGetLastError();
         }
+        // background stream: a narrower partition, so that the chain and the trailing updates keep CUs of their own
+        const char* envb = getenv("PG_BG_CUS");
+        int bgcus = envb ? atoi(envb) : PG_BG_CUS;
+        if (bgcus < 8 || bgcus > ncu - reserved) bgcus = ncu - reserved;
+        for (int i = 0; i < 64; ++i) mask[i] = 0;
+        for (int cu = 0; cu < bgcus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+        if (c->upd && hipExtStreamCreateWithCUMask(&c->bg, (uint32_t)words, mask) != hipSuccess) {
+            c->bg = nullptr;
+            (void)hipGetLastError();
+        }
     }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     *h = c;
@@ -90,6 +100,7 @@ int pg_destroy(pg_handle h) {
     if (!h) return 0;
     (void)hipStreamDestroy(h->aux);
     if (h->upd) (void)hipStreamDestroy(h->upd);
+    if (h->bg) (void)hipStreamDestroy(h->bg);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
     free(h->pool);
@@ -140,8 +151,16 @@ long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
     NEED(h && A && inv_diag && info, "null pointer");
     NEED(lda >= n, "lda < n");
-    DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info),
-             pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info));
+    DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, nullptr, 0),
+             pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info, nullptr, 0));
+}
+
+int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
+                   void* stream) {
+    NEED(h && A && inv_diag && info && Minv, "null pointer");
+    NEED(lda >= n && ldm >= n && A != Minv, "bad leading dimension / aliasing");
+    DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, (double*)Minv, ldm),
+             pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info, (float*)Minv, ldm));
 }
 
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,

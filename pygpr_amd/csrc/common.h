@@ -7,6 +7,7 @@
 
 #define PG_TILE 128      // GEMM block tile and Cholesky leaf size
 #define PG_RESERVED_CUS 32   // default; PG_RESERVED_CUS in the environment overrides
+#define PG_BG_CUS 4096         // CUs the background stream may use, clamped to all non-reserved ones (measured best; PG_BG_CUS overrides)
 #define PG_PAD 256       // every matrix dimension handed to the O(n^3) kernels is a multiple of this
 
 
@@ -15,6 +16,7 @@ typedef float pg_f4 __attribute__((ext_vector_type(4)));
 
 struct pg_ctx {
     hipStream_t aux;          // look-ahead / panel stream (highest priority, non-blocking)
+    hipStream_t bg;           // background stream (same CU mask as upd): L^-1 of the leading half during potrf's tail
     hipStream_t upd;          // trailing-update stream: CU mask leaves PG_RESERVED_CUS compute units to the panel chain
                               // (the 128x128 leaf needs a whole CU's LDS and starves beside a chip-filling SYRK)
     hipEvent_t ev[8];

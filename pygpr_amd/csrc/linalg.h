@@ -1,7 +1,7 @@
 #pragma once
 #include "common.h"
 long pg_potrf_worksize_impl(int n);
-template <typename T> int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info);
+template <typename T> int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm);
 template <typename T> int pg_potrs_vec_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work);
 template <typename T> int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm);
 template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);

@@ -283,128 +283,6 @@ template <typename T> static GemmP<T> gp0() {
 
 long pg_potrf_worksize_impl(int n) { return (long)n * NB; }
 
-static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
-    if (idx >= ctx->npool) {
-        const int want = idx + 16;
-        hipEvent_t* p = (hipEvent_t*)realloc(ctx->pool, sizeof(hipEvent_t) * want);
-        if (!p) { pg_set_error("out of memory for events"); return -3; }
-        ctx->pool = p;
-        for (int i = ctx->npool; i < want; ++i) PG_CHECK(hipEventCreateWithFlags(&ctx->pool[i], hipEventDisableTiming));
-        ctx->npool = want;
-    }
-    *ev = ctx->pool[idx];
-    return 0;
-}
-
-// Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
-// panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
-//   panel stream  (handle's high-priority stream)       : Chain(0)            [wait Sa(0)] Chain(1)        [wait Sa(1)] Chain(2) ...
-//   update stream (handle's CU-masked stream)            :   [wait Chain(0)] Sa(0) Sb(0)     [wait Chain(1)] Sa(1) Sb(1) ...
-// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap.  The update
-// stream may not use the last PG_RESERVED_CUS compute units: the chain's small kernels (and the leaf, which needs a
-// whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
-// the caller's stream at the end.
-template <typename T>
-int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info) {
-    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
-    PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
-    const int NBO = pg_nbo();
-    const int npan = (n + NBO - 1) / NBO;
-    const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
-    hipStream_t ps = la ? ctx->aux : st;   // panel stream
-    hipStream_t us = la ? ctx->upd : st;   // update stream
-    hipEvent_t ev;
-    int rc;
-    if (la) {
-        if ((rc = pool_event(ctx, 0, &ev))) return rc;
-        PG_CHECK(hipEventRecord(ev, st));
-        PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
-        PG_CHECK(hipStreamWaitEvent(us, ev, 0));
-    }
-    for (int o = 0; o < npan; ++o) {
-        const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
-        if (la && o > 0) {   // this panel's columns must have received Sa(o-1)
-            if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
-            PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
-        }
-        for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
-            T* Akk = A + (long)k0 * lda + k0;
-            T* inv = invD + (long)(k0 / NB) * NB * NB;
-            if (k0 > o0) {   // U: bring this column block up to date with the panel's earlier columns
-                GemmP<T> p = gp0<T>(); p.info = info;
-                p.M = n - k0; p.N = NB; p.K = k0 - o0;
-                p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
-                p.alpha = (T)-1; p.beta = (T)1;
-                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64, p))) return rc;
-            }
-            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
-            const int m = n - k0 - NB;
-            if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
-                GemmP<T> p = gp0<T>(); p.info = info;
-                p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
-                p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
-                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64x128, p))) return rc;
-            }
-        }
-        if (oend >= n) break;
-        if (la) {
-            if ((rc = pool_event(ctx, 2 + 2 * o, &ev))) return rc;       // ev_chain[o]
-            PG_CHECK(hipEventRecord(ev, ps));
-            PG_CHECK(hipStreamWaitEvent(us, ev, 0));
-        }
-        const int o2 = std::min(n, oend + NBO);   // first column right of panel o+1
-        {   // Sa(o): panel o+1's columns -= panel o
-            GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
-            p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
-            p.alpha = (T)-1; p.beta = (T)1;
-            // few 128x128 tiles with a 1024-deep K loop leave most CUs idle: use 64x64 tiles then (4x the workgroups)
-            const long tiles = (long)(p.M / 128) * (p.N / 128);
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
-        }
-        if (la) {
-            if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sa[o]
-            PG_CHECK(hipEventRecord(ev, us));
-        }
-        const int m2 = n - o2;
-        if (m2 > 0) {  // Sb(o)
-            T* P = A + (long)o2 * lda + o0;
-            GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
-            p.C = A + (long)o2 * lda + o2; p.ldc = lda;
-            p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
-            const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
-        }
-    }
-    if (la) {   // join both streams back onto the caller's stream
-        if ((rc = pool_event(ctx, 1, &ev))) return rc;
-        PG_CHECK(hipEventRecord(ev, ps));
-        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
-        if ((rc = pool_event(ctx, 2 + 2 * npan, &ev))) return rc;
-        PG_CHECK(hipEventRecord(ev, us));
-        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
-    }
-    return 0;
-}
-
-template <typename T>
-int pg_potrs_vec_t(pg_ctx*, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work) {
-    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrs_vec: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
-    T* w = work;          // running right-hand side of the forward sweep
-    T* z = work + n;      // forward result / running right-hand side of the backward sweep
-    PG_CHECK(hipMemcpyAsync(w, y, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st));
-    const int nb = n / NB;
-    for (int b = 0; b < nb; ++b)      // L z = y
-        hipLaunchKernelGGL(trsv_fwd_step_kernel<T>, dim3(std::max(1, (n - (b + 1) * NB) / 64)), dim3(256), 0, st, L, ldl,
-                           invD + (long)b * NB * NB, b, n, w, z);
-    for (int b = nb - 1; b >= 0; --b) // L^T a = z
-        hipLaunchKernelGGL(trsv_bwd_step_kernel<T>, dim3(std::max(1, (b * NB + 255) / 256)), dim3(256), 0, st, L, ldl,
-                           invD + (long)b * NB * NB, b, z, x);
-    LAUNCH_CHECK();
-    return 0;
-}
-
 template <typename T>
 int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
@@ -445,6 +323,168 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
         if (nfull & 1) rem = rem ? h + rem : h;   // the odd block merges with rem, or becomes the new rem
         h *= 2;
     }
+    return 0;
+}
+
+// Top level of the triangular inverse for the split [0, h1) | [h1, h1 + h2): S = (L21 M11)^T into the mirrored block
+// (first), then M21 = -M22 S^T (second).  The first product only needs L21 and M11.
+template <typename T>
+static int trtri_top(pg_ctx* ctx, hipStream_t st, int h1, int h2, const T* L, long ldl, T* M, long ldm, bool first, bool second) {
+    int rc;
+    if (first) {
+        GemmP<T> p = gp0<T>();
+        p.M = h1; p.N = h2; p.K = h1; p.A = M; p.lda = ldm; p.B = L + (long)h1 * ldl; p.ldb = ldl; p.C = M + h1; p.ldc = ldm; p.klo = 1;
+        if ((rc = pg_gemm<T>(ctx, st, GEMM_TT_128, p))) return rc;
+    }
+    if (second) {
+        GemmP<T> p = gp0<T>();
+        p.M = h2; p.N = h1; p.K = h2; p.A = M + (long)h1 * ldm + h1; p.lda = ldm; p.B = M + h1; p.ldb = ldm;
+        p.C = M + (long)h1 * ldm; p.ldc = ldm; p.alpha = (T)-1; p.khi = 1;
+        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+    }
+    return 0;
+}
+
+static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
+    if (idx >= ctx->npool) {
+        const int want = idx + 16;
+        hipEvent_t* p = (hipEvent_t*)realloc(ctx->pool, sizeof(hipEvent_t) * want);
+        if (!p) { pg_set_error("out of memory for events"); return -3; }
+        ctx->pool = p;
+        for (int i = ctx->npool; i < want; ++i) PG_CHECK(hipEventCreateWithFlags(&ctx->pool[i], hipEventDisableTiming));
+        ctx->npool = want;
+    }
+    *ev = ctx->pool[idx];
+    return 0;
+}
+
+// Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
+// panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
+//   panel stream  (handle's high-priority stream)       : Chain(0)            [wait Sa(0)] Chain(1)        [wait Sa(1)] Chain(2) ...
+//   update stream (handle's CU-masked stream)            :   [wait Chain(0)] Sa(0) Sb(0)     [wait Chain(1)] Sa(1) Sb(1) ...
+// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap.  The update
+// stream may not use the last PG_RESERVED_CUS compute units: the chain's small kernels (and the leaf, which needs a
+// whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
+// the caller's stream at the end.
+template <typename T>
+int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm) {
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
+    const int NBO = pg_nbo();
+    const int npan = (n + NBO - 1) / NBO;
+    const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
+    hipStream_t ps = la ? ctx->aux : st;   // panel stream
+    hipStream_t us = la ? ctx->upd : st;   // update stream
+    hipEvent_t ev;
+    int rc;
+    if (la) {
+        if ((rc = pool_event(ctx, 0, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, st));
+        PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+        PG_CHECK(hipStreamWaitEvent(us, ev, 0));
+    }
+    // fused L^-1: split the diagonal at `split` columns; the leading part is inverted in the background once its
+    // columns are final (after the chain of panel split/NBO - 1), together with the first top-level product
+    const int split = (Minv && la && ctx->bg && npan >= 4) ? (npan / 2) * NBO : 0;
+    for (int o = 0; o < npan; ++o) {
+        const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
+        if (la && o > 0) {   // this panel's columns must have received Sa(o-1)
+            if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
+            PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+        }
+        for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
+            T* Akk = A + (long)k0 * lda + k0;
+            T* inv = invD + (long)(k0 / NB) * NB * NB;
+            if (k0 > o0) {   // U: bring this column block up to date with the panel's earlier columns
+                GemmP<T> p = gp0<T>(); p.info = info;
+                p.M = n - k0; p.N = NB; p.K = k0 - o0;
+                p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
+                p.alpha = (T)-1; p.beta = (T)1;
+                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64, p))) return rc;
+            }
+            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
+            const int m = n - k0 - NB;
+            if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
+                GemmP<T> p = gp0<T>(); p.info = info;
+                p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
+                p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
+                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64x128, p))) return rc;
+            }
+        }
+        if (oend >= n) break;
+        if (la) {
+            if ((rc = pool_event(ctx, 2 + 2 * o, &ev))) return rc;       // ev_chain[o]
+            PG_CHECK(hipEventRecord(ev, ps));
+            PG_CHECK(hipStreamWaitEvent(us, ev, 0));
+            if (split && oend == split) {   // columns [0, split) of L are final in every row
+                PG_CHECK(hipStreamWaitEvent(ctx->bg, ev, 0));
+                if ((rc = pg_trtri_t<T>(ctx, ctx->bg, split, A, lda, invD, Minv, ldm))) return rc;
+                if ((rc = trtri_top<T>(ctx, ctx->bg, split, n - split, A, lda, Minv, ldm, true, false))) return rc;
+            }
+        }
+        const int o2 = std::min(n, oend + NBO);   // first column right of panel o+1
+        {   // Sa(o): panel o+1's columns -= panel o
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
+            p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1;
+            // few 128x128 tiles with a 1024-deep K loop leave most CUs idle: use 64x64 tiles then (4x the workgroups)
+            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+        }
+        if (la) {
+            if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sa[o]
+            PG_CHECK(hipEventRecord(ev, us));
+        }
+        const int m2 = n - o2;
+        if (m2 > 0) {  // Sb(o)
+            T* P = A + (long)o2 * lda + o0;
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
+            p.C = A + (long)o2 * lda + o2; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
+            const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+        }
+    }
+    if (la) {   // join both streams back onto the caller's stream
+        if ((rc = pool_event(ctx, 1, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, ps));
+        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+        if ((rc = pool_event(ctx, 2 + 2 * npan, &ev))) return rc;
+        PG_CHECK(hipEventRecord(ev, us));
+        PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+        if (split) {
+            if ((rc = pool_event(ctx, 3 + 2 * npan, &ev))) return rc;
+            PG_CHECK(hipEventRecord(ev, ctx->bg));
+            PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+        }
+    }
+    if (Minv) {
+        if (!split) return pg_trtri_t<T>(ctx, st, n, A, lda, invD, Minv, ldm);
+        // trailing part of the diagonal, then the second top-level product
+        const long off = split;
+        if ((rc = pg_trtri_t<T>(ctx, st, n - split, A + off * lda + off, lda, invD + (off / NB) * NB * NB, Minv + off * ldm + off, ldm)))
+            return rc;
+        return trtri_top<T>(ctx, st, split, n - split, A, lda, Minv, ldm, false, true);
+    }
+    return 0;
+}
+
+template <typename T>
+int pg_potrs_vec_t(pg_ctx*, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work) {
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrs_vec: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    T* w = work;          // running right-hand side of the forward sweep
+    T* z = work + n;      // forward result / running right-hand side of the backward sweep
+    PG_CHECK(hipMemcpyAsync(w, y, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    const int nb = n / NB;
+    for (int b = 0; b < nb; ++b)      // L z = y
+        hipLaunchKernelGGL(trsv_fwd_step_kernel<T>, dim3(std::max(1, (n - (b + 1) * NB) / 64)), dim3(256), 0, st, L, ldl,
+                           invD + (long)b * NB * NB, b, n, w, z);
+    for (int b = nb - 1; b >= 0; --b) // L^T a = z
+        hipLaunchKernelGGL(trsv_bwd_step_kernel<T>, dim3(std::max(1, (b * NB + 255) / 256)), dim3(256), 0, st, L, ldl,
+                           invD + (long)b * NB * NB, b, z, x);
+    LAUNCH_CHECK();
     return 0;
 }
 
@@ -557,7 +597,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 }
 
 #define INST(T)                                                                                                        \
-    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*);                                         \
+    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long);                               \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long);                         \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \

@@ -82,18 +82,18 @@ class MLE(Loss):
             hp = ops.to_device(torch.from_numpy(np.ascontiguousarray(rows[b % rows.shape[0]])), torch.float64)
             a, out = buf["a"], buf["out"]
             ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
-            ops.potrf(a, buf["invd"], buf["info"])
             if want_grad:
                 if buf["m"] is None:
                     buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
                 m = buf["m"]
-                ops.trtri(a, buf["invd"], m)
+                ops.potrf_trtri(a, buf["invd"], buf["info"], m)      # Cholesky + L^-1, overlapped inside the library
                 ops.trmv(m, e.y, buf["u"], 0)                       # u = L^-1 y
                 ops.trmv(m, buf["u"], buf["alpha"], 1, buf["vwork"])  # alpha = L^-T u
                 ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
                 ops.lauum(m, a)                                     # a <- K^-1 (lower)
                 ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
             else:
+                ops.potrf(a, buf["invd"], buf["info"])
                 ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
                 ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
             res = out.cpu().numpy()                                   # the one sync + transfer

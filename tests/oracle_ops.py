@@ -95,6 +95,11 @@ class OracleOps:
             idx = np.tril_indices(m.shape[0])
             _np(a)[idx] = low[idx]
 
+    def potrf_trtri(self, a, invd, info, minv):
+        self.potrf(a, invd, info)
+        if int(info[0]) == 0:
+            self.trtri(a, invd, minv)
+
     def potrs_vec(self, chol, invd, y, x, work=None):
         x.copy_(torch.from_numpy(sla.cho_solve((np.tril(_np(chol).astype(np.float64)), True), _np(y).astype(np.float64),
                                               check_finite=False)))

@@ -228,6 +228,29 @@ def test_potrf_lookahead_matches_sequential(ops):
     np.testing.assert_allclose(outs[0], np.linalg.cholesky(a), atol=1e-11)
 
 
+def test_potrf_trtri_fused_matches_separate(ops):
+    """n = 4096 has four outer panels: the fused call inverts the leading half on the background stream while the
+    Cholesky's tail runs; factor and inverse must equal the separate calls bit for bit."""
+    rng = np.random.default_rng(44)
+    n = 4096
+    a = spd(n, rng)
+    ad, bd = dev(a), dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd = ops.potrf_workspace(n, torch.float64)
+    m1, m2 = ops.zeros(n, n), ops.zeros(n, n)
+    ops.potrf_trtri(ad, invd, info, m1)
+    assert int(info.item()) == 0
+    invd2 = ops.potrf_workspace(n, torch.float64)
+    ops.potrf(bd, invd2, info)
+    ops.trtri(bd, invd2, m2)
+    assert np.array_equal(np.tril(host(ad)), np.tril(host(bd)))
+    g1, g2 = np.tril(host(m1)), np.tril(host(m2))
+    assert np.array_equal(g1, g2)
+    chol = np.linalg.cholesky(a)
+    v = rng.standard_normal(n)
+    np.testing.assert_allclose(g1 @ (chol @ v), v, atol=1e-9)
+
+
 def test_potrf_not_positive_definite_reports_minor(ops):
     rng = np.random.default_rng(4)
     n = 512

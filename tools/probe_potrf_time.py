@@ -19,3 +19,16 @@ for n in (8192, 16384):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); run(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
         print(f"n={n} lookahead={la} build+potrf {best:.2f} ms -> potrf ~{n**3/3/(best-0.45*(n/16384)**2)/1e9:.1f} TF/s info={int(info.item())}", flush=True)
+    minv = ops.empty(n, n)
+    def fused():
+        ops.kernel_build(spec, hp, x, None, kl, lower_only=True, jitter=1e-7); ops.potrf_trtri(kl, invd, info, minv)
+    def sep():
+        ops.kernel_build(spec, hp, x, None, kl, lower_only=True, jitter=1e-7); ops.potrf(kl, invd, info); ops.trtri(kl, invd, minv)
+    ops.set_lookahead(1)
+    for name, fn in (("separate", sep), ("fused", fused)):
+        fn(); torch.cuda.synchronize(); best = 1e9
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
+        print(f"n={n} build+potrf+trtri {name}: {best:.2f} ms", flush=True)
+    del minv
