@@ -79,11 +79,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; PG_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
+    # single-GPU box -- RCCL refuses two ranks on one device)
+    backend = os.environ.get("PG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import pygpr_amd as pg
     from pygpr_amd._ops import get_ops, make_spec
@@ -116,10 +123,14 @@ def main():
         val, grad = loss.loss_and_grad(hp)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+
+    elapsed = max_over_ranks(elapsed)
     value = world * args.steps / elapsed
 
     out = {
@@ -137,8 +148,10 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: one profiled evaluation (events around every GEMM launch)
+        local = pg.MLE(model.gpl)            # rank-local evaluation: no collective inside a rank-0-only section
+        local.loss_and_grad(hp[None, :].copy())
         ops.profile(1)
-        loss.loss_and_grad(hp)
+        local.loss_and_grad(hp[None, :].copy())
         torch.cuda.synchronize()
         ops.profile(0)
         flops, ms, launches = ops.profile_read()
@@ -212,10 +225,7 @@ def main():
             mu, var = g4.predict(xs[s: s + mb])
         barrier()
         tp = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([tp], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tp = float(tt.item())
+        tp = max_over_ranks(tp)
         out["grbcm_predict"] = {
             "value": m4 / tp, "unit": "points/s", "scaling": "strong", "seconds": tp,
             "config": "8 experts x (%d global + %d local) points, D=%d, RBF+noise fp64, %d test points in batches of %d, "

@@ -12,7 +12,7 @@ def ev(fn, reps=5):
 n = 16384
 g = torch.Generator(device="cuda").manual_seed(1)
 c = torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g)
-for K in (1024,):
+for K in (256, 1024, 4096):
     p = torch.randn(n, K, device="cuda", dtype=torch.float64, generator=g)
     t = ev(lambda: ops.gemm_raw(GEMM_NT, n, n, K, -1.0, p, p, 1.0, c, tri=1))
     print(f"syrk lower n={n} K={K}: {t:.3f} ms {n*(n+128)*K/t/1e9:.1f} TF/s", flush=True)
