@@ -156,6 +156,9 @@ int pg_set_lookahead(pg_handle h, int on);
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
 
+/* one 128x128 Cholesky leaf (factor + inverse) on its own; ablate != 0 skips phases -- timing diagnostics only */
+int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream);
+
 /* raw MFMA GEMM core, exposed for tests and the roofline micro-benchmark:
  * variant 0: C = a A B^T + b C (128x128 tiles; tri != 0 -> lower tiles only), 2: C = a A B + b C,
  * 3: C = a A^T B + b C.  klo/khi as in csrc/gemm.h. */

@@ -224,6 +224,11 @@ class HipOps:
     def set_lookahead(self, on):
         _lib.check(self.lib.pg_set_lookahead(self.h, int(on)), "pg_set_lookahead")
 
+    def leaf_raw(self, a, inv, info, ablate=0):
+        self._chk(a, inv, info)
+        _lib.check(self.lib.pg_leaf_raw(self.h, _code(a.dtype), _p(a), a.stride(0), _p(inv), inv.stride(0) if inv is not None else 0,
+                                        _p(info), int(ablate), self._st()), "pg_leaf_raw")
+
     def profile(self, on):
         _lib.check(self.lib.pg_profile(self.h, int(on)), "pg_profile")
 

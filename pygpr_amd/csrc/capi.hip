@@ -1,6 +1,7 @@
 // extern "C" surface of libpygpr_hip (declared in include/pygpr_hip.h): argument checks, dtype dispatch.
 #include "gemm.h"
 #include "kbuild.h"
+#include "leaf.h"
 #include "linalg.h"
 #include <cstdarg>
 #include <cstdio>
@@ -325,6 +326,12 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
     if (ms) *ms = h->prof_ms;
     if (launches) *launches = h->prof_launches;
     return 0;
+}
+
+int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream) {
+    NEED(h && A && info, "null pointer");
+    DISPATCH(dtype, pg_leaf<double>(ST(stream), (double*)A, lda, (double*)inv, ldi, info, 0, ablate),
+             pg_leaf<float>(ST(stream), (float*)A, lda, (float*)inv, ldi, info, 0, ablate));
 }
 
 int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,

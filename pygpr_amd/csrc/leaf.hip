@@ -1,14 +1,13 @@
-// Cholesky leaf: factor one 128x128 diagonal block entirely in LDS (one 256-thread workgroup) and produce
+// Cholesky leaf: factor one 128x128 diagonal block entirely in LDS (one workgroup) and produce
 // its inverse, which turns every triangular solve above it into an MFMA GEMM.
 //
 // Blocked right-looking with 16-wide micro-panels, software-pipelined; per micro-panel jb:
-//   A. wave 0 factors the 16x16 diagonal block AND inverts it in one pass over its columns, in REGISTERS: lane r
-//      holds row r of D and row r of X = D^-1; per column the pivot, the multipliers and the finished row c of X
-//      are broadcast with v_readlane (1/sqrt by v_rsq + 2 Newton steps).  A non-positive / NaN pivot sets
+//   A. wave 0 factors the 16x16 diagonal block in REGISTERS: lane r holds row r; per column the pivot and the
+//      multipliers are broadcast with v_readlane (1/sqrt by v_rsq + 2 Newton steps).  A non-positive / NaN pivot sets
 //      *info = global column + 1 (LAPACK convention, first failure wins) and stops.
-//      Meanwhile waves 1..3 finish the trailing update of the PREVIOUS micro-panel (all tiles except its first
+//      Meanwhile the other waves finish the trailing update of the PREVIOUS micro-panel (all tiles except its first
 //      tile column), which nothing in A or B depends on.
-//   B. panel solve  P <- P inv(D)^T  for the rows below, 16x16x4 MFMAs on LDS operands
+//   B. panel solve  P <- P D^-T  by forward substitution, one thread per row (D broadcast from LDS)
 //   C. first tile column of the trailing update  T <- T - P P^T  (next diagonal block + next panel), MFMA
 // The inverse of the whole block then follows by recursive doubling from the eight 16x16 inverses:
 // X21 = -X22 (L21 X11), level by level (16, 32, 64), again MFMA on LDS; the mirrored (upper) block is
@@ -18,6 +17,8 @@
 #define NB 128
 #define LD 130
 #define DLD 18
+#define NTH 512     // 8 waves: wave 0 runs the serial diagonal step, the MFMA phases are spread over all of them
+#define NWV (NTH / 64)
 
 template <typename T> __device__ __forceinline__ T bcast_lane(T v, int src);
 template <> __device__ __forceinline__ double bcast_lane<double>(double v, int src) {
@@ -70,8 +71,8 @@ __device__ __forceinline__ void lds_tile_mm(T* C, int ldc, const T* A, int lda, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                                      int* __restrict__ info, int col0) {
+__global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
+                                                      int* __restrict__ info, int col0, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* S = reinterpret_cast<T*>(smem_raw);
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
     if (*info != 0) return;
     if (tid == 0) fail = 0;
     typedef T pair_t __attribute__((ext_vector_type(2)));
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {       // two columns per thread, 64 pairs per row
+    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {       // two columns per thread, 64 pairs per row
         const int i = idx >> 6, k = (idx & 63) * 2;
         pair_t v = {(T)0, (T)0};
         if (k <= i) {
@@ -92,15 +93,16 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
     }
     __syncthreads();
 
-    for (int jb = 0; jb < NB / 16; ++jb) {
+    T* Rd = Dinv + 8 * 16 * DLD + 2;   // [16] reciprocals of the current diagonal block's diagonal (behind the flag)
+    for (int jb = 0; jb < ((ablate & 1) ? 0 : NB / 16); ++jb) {   // ablate bit 0: skip the factorisation loop
         const int c0 = jb * 16, r0 = c0 + 16;
-        if (wave == 0) {
-            // ---- A: diagonal 16x16 block: factor + inverse fused, registers of wave 0
+        if (wave == 0 && !(ablate & 8)) {   // bit 3: skip the diagonal step
+            // ---- A: factor the 16x16 diagonal block in registers of wave 0 (lane r = row r)
             const int r = lane & 15;
             T* D = S + c0 * LD + c0;
-            T row[16], xr[16];
+            T row[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { row[c] = D[r * LD + c]; xr[c] = (c == r) ? (T)1 : (T)0; }
+            for (int c = 0; c < 16; ++c) row[c] = D[r * LD + c];
             bool ok = true;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -112,29 +114,20 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
                 const T rs = ok ? inv_sqrt(piv) : (T)0;
                 const T lrc = row[c] * rs;           // lane c: sqrt(piv); lanes r < c: 0 (upper part is zero)
                 row[c] = lrc;
+                if (lane == c) Rd[c] = rs;
 #pragma unroll
                 for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
-                // row c of X is complete once scaled by 1/l_cc (xc); rows below eliminate it: x_r -= l_rc xc.
-                // Lane c itself must end up with xc = x_c rs: x_c - (l_cc - 1) xc = x_c rs (l_cc rs = 1), so one masked
-                // multiplier serves all three cases and the loop is a plain broadcast + fma.
-                const T mult = (r > c) ? lrc : ((r == c) ? lrc - (T)1 : (T)0);
-#pragma unroll
-                for (int j = 0; j <= c; ++j) xr[j] -= mult * (bcast_lane(xr[j], c) * rs);
             }
             if (lane < 16) {
-                T* Dv = Dinv + jb * 16 * DLD;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    D[r * LD + c] = (c <= r) ? row[c] : (T)0;
-                    Dv[r * DLD + c] = (c <= r) ? xr[c] : (T)0;
-                }
+                for (int c = 0; c < 16; ++c) D[r * LD + c] = (c <= r) ? row[c] : (T)0;
             }
         } else if (jb > 0) {
             // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti
             const int pc0 = c0 - 16, pr0 = c0;           // previous panel's columns / first trailing row
             const int pnt = (NB - pr0) / 16;
             const int nrest = pnt * (pnt - 1) / 2;       // pairs (ti, tj): 1 <= tj <= ti <= pnt - 1
-            for (int t = wave - 1; t < nrest; t += 3) {
+            for (int t = wave - 1; t < nrest; t += NWV - 1) {
                 int u = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
                 while (u * (u + 1) / 2 > t) --u;
                 while ((u + 1) * (u + 2) / 2 <= t) ++u;
@@ -147,31 +140,60 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
         if (fail) return;
         if (r0 >= NB) break;
         const int nt = (NB - r0) / 16;   // 16-row tiles below the diagonal block
-        // ---- B: P <- P inv(D)^T
-        for (int t = wave; t < nt; t += 4)
-            lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + c0, LD, S + (r0 + t * 16) * LD + c0, LD, Dinv + jb * 16 * DLD,
-                                 DLD, 16, (T)1, (T)0, lane);
+        // ---- B: P <- P D^-T by forward substitution, one thread per row; D and 1/diag are broadcast reads from LDS
+        if (tid < NB - r0) {
+            T* Prow = S + (r0 + tid) * LD + c0;
+            const T* D = S + c0 * LD + c0;
+            T x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = Prow[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                T sacc = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sacc -= x[k] * D[c * LD + k];
+                x[c] = sacc * Rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Prow[c] = x[c];
+        }
         __syncthreads();
         // ---- C (first tile column): next diagonal block and next panel, T <- T - P P^T
-        for (int t = wave; t < nt; t += 4)
+        for (int t = wave; t < nt; t += NWV)
             lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + r0, LD, S + (r0 + t * 16) * LD + c0, LD, S + r0 * LD + c0, LD, 16,
                                  (T)-1, (T)1, lane);
         __syncthreads();
     }
 
     // L back to global (diagonal tiles of C above wrote the strictly upper 16x16 corners: mask them)
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
         const int i = idx >> 6, k = (idx & 63) * 2;
         pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
         if (k > i) v[0] = (T)0;
         if (k + 1 > i) v[1] = (T)0;
         *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
     }
-    if (inv == nullptr) return;
+    if (inv == nullptr || (ablate & 2)) return;   // bit 1: skip the inverse
     __syncthreads();
 
-    // ---- inverse, level 0: drop the 16x16 inverses on the diagonal, clear everything above it
-    for (int idx = tid; idx < NB * NB; idx += 256) {
+    // ---- inverse, level 0: the eight 16x16 diagonal inverses, one per wave (lane c solves D x = e_c with broadcast
+    // reads of D); then drop them on the diagonal and clear everything above it
+    if (wave < 8 && lane < 16) {
+        const T* D = S + (wave * 16) * LD + wave * 16;
+        T x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            T sacc = (i == lane) ? (T)1 : (T)0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc -= D[i * LD + k] * x[k];
+            x[i] = sacc / D[i * LD + i];
+        }
+        T* Dv = Dinv + wave * 16 * DLD;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Dv[i * DLD + lane] = x[i];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += NTH) {
         const int i = idx >> 7, k = idx & 127;
         if (k > i) S[i * LD + k] = (T)0;
         else if ((i >> 4) == (k >> 4)) S[i * LD + k] = Dinv[(i >> 4) * 16 * DLD + (i & 15) * DLD + (k & 15)];
@@ -179,10 +201,10 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
     __syncthreads();
 
     // ---- levels s = 16, 32, 64: X21 = -X22 (L21 X11)
-    for (int s = 16; s < NB; s <<= 1) {
+    for (int s = 16; s < ((ablate & 4) ? 0 : NB); s <<= 1) {   // bit 2: skip the doubling levels
         const int tps = s / 16;
         const int tiles = (NB / (2 * s)) * tps * tps;
-        for (int t = wave; t < tiles; t += 4) {
+        for (int t = wave; t < tiles; t += NWV) {
             const int pr = t / (tps * tps), tt = t % (tps * tps), bi = tt / tps, bj = tt % tps;
             const int q0 = pr * 2 * s;
             lds_tile_mm<T, false>(S + (q0 + bi * 16) * LD + q0 + s + bj * 16, LD,      // scratch tile (mirror)
@@ -190,7 +212,7 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
                                   S + q0 * LD + q0 + bj * 16, LD, s, (T)1, (T)0, lane);   // X11 cols
         }
         __syncthreads();
-        for (int t = wave; t < tiles; t += 4) {
+        for (int t = wave; t < tiles; t += NWV) {
             const int pr = t / (tps * tps), tt = t % (tps * tps), bi = tt / tps, bj = tt % tps;
             const int q0 = pr * 2 * s;
             lds_tile_mm<T, false>(S + (q0 + s + bi * 16) * LD + q0 + bj * 16, LD,      // X21 tile
@@ -198,20 +220,20 @@ __global__ __launch_bounds__(256) void pg_leaf_kernel(T* __restrict__ A, long ld
                                   S + q0 * LD + q0 + s + bj * 16, LD, s, (T)-1, (T)0, lane);   // scratch cols
         }
         __syncthreads();
-        for (int idx = tid; idx < (NB / (2 * s)) * s * s; idx += 256) {
+        for (int idx = tid; idx < (NB / (2 * s)) * s * s; idx += NTH) {
             const int pr = idx / (s * s), e = idx % (s * s), i = e / s, k = e % s;
             S[(pr * 2 * s + i) * LD + pr * 2 * s + s + k] = (T)0;
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
         const int i = idx >> 6, k = (idx & 63) * 2;
         *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = *reinterpret_cast<const pair_t*>(S + i * LD + k);
     }
 }
 
-template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0) {
-    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD) * sizeof(T) + 16;
+template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
+    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     auto kern = pg_leaf_kernel<T>;
     if (!attr_done) {
@@ -219,9 +241,9 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, st, A, lda, inv, ldi, info, col0);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_leaf<double>(hipStream_t, double*, long, double*, long, int*, int);
-template int pg_leaf<float>(hipStream_t, float*, long, float*, long, int*, int);
+template int pg_leaf<double>(hipStream_t, double*, long, double*, long, int*, int, int);
+template int pg_leaf<float>(hipStream_t, float*, long, float*, long, int*, int, int);
