@@ -83,20 +83,24 @@ class GPR:
 class _Expert:
     """Device state of one expert."""
 
-    __slots__ = ("x", "y", "n", "n_pad", "chol", "invd", "alpha", "minv", "hp", "info")
+    __slots__ = ("x", "y", "n", "n_pad", "chol", "invd", "alpha", "minv", "minv_valid", "work", "hp", "info")
 
     def __init__(self):
-        self.chol = self.invd = self.alpha = self.minv = self.hp = self.info = None
+        self.chol = self.invd = self.alpha = self.minv = self.work = self.hp = self.info = None
+        self.minv_valid = False
 
 
 class Exact_GP(GPR):
     """Exact GP model (PyGPR/gpr.py:46-120); x [(nc), n, d], y [(nc), n], params [(nc), nhp]."""
 
-    def __init__(self, x: Tensor, y: Tensor, cov: Covar) -> None:
+    def __init__(self, x: Tensor, y: Tensor, cov: Covar, eager_inverse: bool = False) -> None:
         super().__init__(x, y, cov)
         self.params: Tensor = cov.init_params(x)
         self._experts = None
         self.need_upd: bool = True
+        # eager_inverse: form L^-1 inside update() (fused with the Cholesky) and take alpha = L^-T (L^-1 y) from two
+        # triangular mat-vecs.  Worth it whenever predictive variances follow (grBCM experts); wasted work otherwise.
+        self.eager_inverse = eager_inverse
         return None
 
     # ---- device residency -------------------------------------------------------------------
@@ -149,10 +153,20 @@ class Exact_GP(GPR):
                     e.invd = ops.potrf_workspace(e.n_pad, self.dtype)
                     e.alpha = ops.empty(e.n_pad, dtype=self.dtype)
                     e.info = torch.zeros(1, dtype=torch.int32, device=ops.device)
-                e.minv = None
                 ops.kernel_build(spec, e.hp, e.x, None, e.chol, lower_only=True, jitter=JITTER)
-                ops.potrf(e.chol, e.invd, e.info)
-                ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
+                if self.eager_inverse:
+                    if e.minv is None:
+                        e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+                        e.work = ops.empty((e.n_pad // 256 + 1) * e.n_pad, dtype=self.dtype)
+                    ops.potrf_trtri(e.chol, e.invd, e.info, e.minv)
+                    u = e.work[: e.n_pad]
+                    ops.trmv(e.minv, e.y, u, 0)
+                    ops.trmv(e.minv, u, e.alpha, 1, e.work[e.n_pad:])
+                    e.minv_valid = True
+                else:
+                    e.minv_valid = False
+                    ops.potrf(e.chol, e.invd, e.info)
+                    ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
             for e in experts:   # one sync point after everything is enqueued
                 info = int(e.info.item())
                 if info:
@@ -161,10 +175,12 @@ class Exact_GP(GPR):
         return None
 
     def _minv(self, e):
-        if e.minv is None:
+        if not e.minv_valid:
             ops = get_ops()
-            e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+            if e.minv is None:
+                e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
             ops.trtri(e.chol, e.invd, e.minv)
+            e.minv_valid = True
         return e.minv
 
     def _kss_diag(self, b: int) -> float:

@@ -65,8 +65,9 @@ class GRBCM(GPR):
         y = torch.cat((yg.unsqueeze(0).expand(nloc, ng), yls), dim=1)
 
         self.cov = cov
-        self.gpg = Exact_GP(xg, yg, cov)                                    # gr_bcm.py:28
-        self.gpl = Exact_GP(x, y, cov) if nloc else None                    # gr_bcm.py:29 (owned experts)
+        # the committee always needs predictive variances, so the experts form L^-1 while they factorise
+        self.gpg = Exact_GP(xg, yg, cov, eager_inverse=True)                # gr_bcm.py:28
+        self.gpl = Exact_GP(x, y, cov, eager_inverse=True) if nloc else None    # gr_bcm.py:29 (owned experts)
 
         self.nc = nc
         self.nsc = nls

@@ -132,6 +132,13 @@ def test_exact_gp_golden(golden):
 
 def test_exact_gp_cfg1_and_batched(golden):
     g = golden("gp")
+    for eager in (False, True):                    # alpha by blocked substitution / by L^-T (L^-1 y): same answers
+        gpe = pg.Exact_GP(T(g["a_x"]), T(g["a_y"]), se_wn(), eager_inverse=eager)
+        gpe.set_params(T(g["a_hp"]))
+        mu, var = gpe.predict(T(g["a_xp"]), var="diag")
+        np.testing.assert_allclose(N(mu), g["a_mu"], atol=1e-10)
+        np.testing.assert_allclose(N(var), g["a_var"], atol=1e-11)
+        np.testing.assert_allclose(N(gpe.wt), g["a_wt"], rtol=1e-8)
     gp = pg.Exact_GP(T(g["b_x"]), T(g["b_y"]), se_wn())
     gp.set_params(T(g["b_hp"]))
     mu, var = gp.predict(T(g["b_xp"]), var="diag")
