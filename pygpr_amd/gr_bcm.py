@@ -216,6 +216,15 @@ class GRBCM_MLE(Loss):
         super().__init__(model)
         self._mle = MLE(model.gpl) if model.gpl is not None else None
 
+    @property
+    def memoize(self):
+        return self._mle.memoize if self._mle is not None else False
+
+    @memoize.setter
+    def memoize(self, on):
+        if self._mle is not None:
+            self._mle.memoize = bool(on)
+
     def _reduce(self, vec):
         g = self.model
         if g.distributed:

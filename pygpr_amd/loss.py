@@ -45,6 +45,8 @@ class MLE(Loss):
     def __init__(self, model: GPR) -> None:
         super().__init__(model)
         self._buf = {}
+        self.memoize = True     # re-use the last evaluation when asked again at identical parameters (off in benchmarks)
+        self._memo = None
 
     def _buffers(self, n_pad, dtype, nhp, n):
         key = (n_pad, dtype, nhp, n)
@@ -65,6 +67,17 @@ class MLE(Loss):
         return self._buf
 
     def _evaluate(self, params: ndarray, want_grad: bool):
+        """One evaluation, memoised on (parameters, data identity): the reference re-factorises on every call
+        (loss.py:39,64,97); CG_Quad / BFGS_Quad / hessian ask for grad(par) at the same point again and again."""
+        key = (np.asarray(params, dtype=np.float64).tobytes(), np.shape(params), id(self.model._x), id(self.model._y))
+        hit = self._memo if (self.memoize and self._memo is not None and self._memo[0] == key) else None
+        if hit is not None and (hit[2] is not None or not want_grad):
+            return hit[1].copy(), (hit[2].copy() if hit[2] is not None else None)
+        loss, grad = self._evaluate_device(params, want_grad)
+        self._memo = (key, loss.copy(), grad.copy() if want_grad else None)
+        return loss, grad
+
+    def _evaluate_device(self, params: ndarray, want_grad: bool):
         ops = get_ops()
         model = self.model
         d = model.x.shape[-1]

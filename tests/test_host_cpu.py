@@ -78,6 +78,16 @@ def test_host_logic_against_golden(fake_ops, golden):
     loss, grad = pg.MLE(gp).loss_and_grad(g["a_hp"].copy())
     np.testing.assert_allclose(loss, g["a_loss2"], rtol=1e-10)
     np.testing.assert_allclose(grad, g["a_grad2"], rtol=1e-8, atol=1e-8)
+    # memo: the same parameters are not evaluated twice; new parameters or new data are
+    calls = []
+    mle = pg.MLE(gp)
+    orig = mle._evaluate_device
+    mle._evaluate_device = lambda p, w: (calls.append(w), orig(p, w))[1]
+    g1 = mle.grad(g["a_hp"].copy()); l1 = mle.loss(g["a_hp"].copy()); g2 = mle.grad(g["a_hp"].copy())
+    assert calls == [True] and np.array_equal(g1, g2) and float(l1) == float(mle.loss_and_grad(g["a_hp"].copy())[0])
+    mle.loss(g["a_hp"] * 1.01)
+    mle.grad(g["a_hp"] * 1.01)            # a loss-only result cannot serve a gradient request
+    assert calls == [True, False, True]
     # batched experts: shapes and squeeze rules
     gpc = pg.Exact_GP(T(g["c_x"]), T(g["c_y"]), se_wn())
     gpc.set_params(T(g["c_hp"]))

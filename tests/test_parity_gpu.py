@@ -207,6 +207,8 @@ def test_mle_golden(golden):
     np.testing.assert_allclose(l2, g["a_loss2"], rtol=1e-10)
     np.testing.assert_allclose(g2, g["a_grad2"], rtol=1e-8, atol=1e-8 * np.abs(g["a_grad2"]).max())
     assert mle.loss_value is l2 and mle.grad_value is g2
+    l3, g3 = mle.loss_and_grad(g["a_hp"].copy())          # memoised repeat: same numbers without a device evaluation
+    assert float(l3) == float(l2) and np.array_equal(g3, g2)
     l0, g0 = mle.loss_and_grad(g["a_hp0"].copy())                      # cond(K) ~ 1e9
     np.testing.assert_allclose(l0, g["a_loss0"], rtol=1e-8)
     np.testing.assert_allclose(g0, g["a_grad0"], rtol=1e-5, atol=1e-5 * np.abs(g["a_grad0"]).max())
