@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
         const int tn = p.N / BN;
         ti = wg / tn;
         tj = wg % tn;
+        if (p.khi == 1) ti = p.M / BM - 1 - ti;   // K grows with the tile row: launch the long rows first
     }
     const long zb = blockIdx.y;
     const T* __restrict__ A = p.A + zb * p.sA;
