@@ -12,6 +12,7 @@ Extra objects on the same JSON line:
   roofline      the MFMA GEMM core (all instantiations of pg_gemm_kernel) over one evaluation: algorithmic
                 flop of its launches / summed launch durations measured with HIP events inside the library
                 (pg_profile), against the fp64 matrix peak; plus potrf alone and the covariance build (HBM)
+  cpu_baseline_as_written  the reference's algorithm as written (dK stack + batched cholesky_solve), N=4096, n^3-scaled
   cpu_baseline  the CPU oracle's lean K^-1-route evaluation (oracle/pygpr_oracle.py, torch CPU + LAPACK) timed
                 on this host's cores at a bounded size and n^3-scaled to N = 16384
   grbcm_predict BASELINE config 4 (8 experts x (1024 + 8192) points, D = 16, 65536 test points): committee
@@ -61,6 +62,27 @@ def cpu_baseline(n_full, d, n_cpu):
     }
 
 
+def cpu_baseline_as_written(n_full, d, n_cpu):
+    """Oracle (kind = "port") of the reference's algorithm AS WRITTEN (dK stack + batched cholesky_solve,
+    n^3/3 + 2 nhp n^3 flop), n^3-scaled to n_full.  SURVEY 8d variant A; reported next to cpu_baseline."""
+    from oracle import pygpr_oracle as orc
+
+    x, y = synth_expert(n_cpu, d, 1234)
+    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
+    t0 = time.perf_counter()
+    orc.mle_loss_and_grad_as_written(hp, x, y)
+    t = time.perf_counter() - t0
+    scale = (n_full / n_cpu) ** 3
+    cores = torch.get_num_threads()
+    return {
+        "value": 1.0 / (t * scale), "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": "1 as-written NLML+grad eval (oracle.mle_loss_and_grad_as_written: torch CPU fp64, dK stack + batched "
+                  "cholesky_solve, %d intra-op threads) at N=%d D=%d took %.2f s; n^3-scaled x%.0f to N=%d (extrapolated)"
+                  % (cores, n_cpu, d, t, scale, n_full),
+        "seconds_measured": t,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +92,7 @@ def main():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--ng", type=int, default=1024, help="size of the grBCM global/communication set")
     ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n-written", type=int, default=4096, help="size of the as-written CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grbcm", action="store_true")
     args = ap.parse_args()
@@ -226,6 +249,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d, min(args.cpu_n, n))
             out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
+            out["cpu_baseline_as_written"] = cpu_baseline_as_written(n, d, min(args.cpu_n_written, n))
 
     # ---- secondary metric: grBCM committee prediction throughput (BASELINE config 4)
     if not args.no_grbcm:

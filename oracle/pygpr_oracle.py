@@ -19,6 +19,7 @@ instead.
 Two flavours are kept for the O(n^3) gradient:
   * `mle_loss_and_grad(..., route="solve")`  -- reference-faithful: materialise
     dK[nhp,n,n] and cho_solve it (PyGPR/loss.py:92-128), cost n^3/3 + 2 nhp n^3;
+  * `mle_loss_and_grad_as_written` -- the same as-written algorithm on torch CPU (second bench baseline),
   * `route="kinv"` -- the lean K^-1 route (g_k = 1/2 sum (K^-1 - a a^T) o dK_k),
     the same mathematics the HIP path runs; cost ~ n^3.
 """
@@ -307,6 +308,37 @@ def mle_loss_and_grad_lean(hp, x, y):
     g[1:d + 1] = (0.5 * -2.0 * ls * quad).numpy()
     g[d + 1] = 0.5 * 2.0 * sn * tr_w
     return loss, g
+
+
+def mle_loss_and_grad_as_written(hp, x, y):
+    """Second CPU baseline for bench.py (Compose([SE, WN]) only): the reference's algorithm AS WRITTEN, on its
+    own substrate (torch CPU fp64): the dK stack [nhp,n,n] is materialised (covar.py:169-206, 247-269), and
+    tr(K^-1 dK_k) comes from one batched cholesky_solve on the whole stack (loss.py:92-128, solve at :116).
+    Cost n^3/3 + 2 nhp n^3.  Same numbers as mle_loss_and_grad(route="solve") to rounding."""
+    import torch
+
+    n, d = x.shape
+    xt, yt = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(y))
+    sig, sn = float(hp[0]), float(hp[d + 1])
+    ls = torch.from_numpy(np.ascontiguousarray(hp[1:d + 1]))
+    xl = xt * ls
+    x2 = (xl * xl).sum(1)
+    k = torch.addmm(x2[:, None] + x2[None, :], xl, xl.T, alpha=-2.0)        # covar.py:102-127
+    k.neg_().exp_().mul_(sig * sig)                                            # covar.py:147-149
+    dk = torch.empty(d + 2, n, n, dtype=torch.float64)
+    dk[0] = k * (2.0 / sig)                                                    # covar.py:189
+    xc = xt.T.contiguous()
+    for a in range(d):                                                         # covar.py:191-199
+        diff = xc[a][:, None] - xc[a][None, :]
+        dk[a + 1] = diff.mul_(diff).mul_(k).mul_(-2.0 * float(ls[a]))
+    dk[d + 1] = torch.eye(n, dtype=torch.float64) * (2.0 * sn)                 # covar.py:262-264
+    k.diagonal().add_(sn * sn + JITTER)
+    chol = torch.linalg.cholesky(k)
+    alpha = torch.cholesky_solve(yt[:, None], chol)[:, 0]
+    loss = 0.5 * float(alpha @ yt) + float(torch.log(chol.diagonal()).sum()) + 0.5 * n * np.log(2.0 * np.pi)
+    tr1 = torch.einsum("i,kij,j->k", alpha, dk, alpha)
+    tr2 = torch.cholesky_solve(dk, chol).diagonal(dim1=-2, dim2=-1).sum(-1)   # loss.py:116-119
+    return loss, (-0.5 * (tr1 - tr2)).numpy()
 
 
 def get_learn_rate(covs, hp, x, y, eps, form="gemm"):

@@ -165,3 +165,18 @@ def test_matern52_unpinned_by_reference_matches_sklearn():
         e[a] = 1e-6
         fd = (orc.matern52_kernel(hp + e, x) - orc.matern52_kernel(hp - e, x)) / 2e-6
         np.testing.assert_allclose(dk[a], fd, atol=1e-8)
+
+
+def test_as_written_torch_baseline_matches_solve_route():
+    """bench.py's second CPU baseline (torch substrate) is the same function as the as-written oracle route."""
+    rng = np.random.default_rng(5)
+    n, d = 96, 3
+    x = rng.random((n, d))
+    y = np.sin(-x.sum(1)) + 0.1 * rng.standard_normal(n)
+    hp = np.concatenate([[1.3], 0.5 + rng.random(d), [0.1]])
+    f0, g0 = orc.mle_loss_and_grad([orc.SE(), orc.WN()], hp, x, y, route="solve")
+    f1, g1 = orc.mle_loss_and_grad_as_written(hp, x, y)
+    f2, g2 = orc.mle_loss_and_grad_lean(hp, x, y)
+    assert abs(f0 - f1) <= 1e-11 * abs(f0) and abs(f0 - f2) <= 1e-11 * abs(f0)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
+    np.testing.assert_allclose(g2, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
