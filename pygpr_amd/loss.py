@@ -92,7 +92,7 @@ class MLE(Loss):
         for b in range(nb):
             e = experts[b % len(experts)]
             buf = self._buffers(e.n_pad, model.dtype, nhp, e.n)
-            hp = ops.to_device(torch.from_numpy(np.ascontiguousarray(rows[b % rows.shape[0]])), torch.float64)
+            hp = ops.to_device(torch.from_numpy(np.array(rows[b % rows.shape[0]], dtype=np.float64)), torch.float64)
             a, out = buf["a"], buf["out"]
             ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
             if want_grad:
