@@ -371,6 +371,19 @@ def test_fp32_opt_in():
     np.testing.assert_allclose(grad, g_ref, rtol=2e-2, atol=2e-2 * np.abs(g_ref).max())
 
 
+def test_fp32_tracks_fp64_at_scale():
+    """BASELINE config 5's regime at a size with 32 outer panels: the fp32 path against the fp64 HIP path (itself
+    pinned against the oracle above) on the same data -- rtol 1e-3 class, sigma_n = 0.1."""
+    n, d = 8192, 16
+    x, y = orc.synth(n, d, seed=77)
+    hp = np.concatenate([[1.0], np.full(d, 0.5), [0.1]])
+    cov = pg.Compose([pg.Matern52(), pg.White_noise()])
+    l64, g64 = pg.MLE(pg.Exact_GP(T(x), T(y), cov)).loss_and_grad(hp.copy())
+    l32, g32 = pg.MLE(pg.Exact_GP(T(x).float(), T(y).float(), cov)).loss_and_grad(hp.copy())
+    np.testing.assert_allclose(l32, l64, rtol=1e-3)
+    np.testing.assert_allclose(g32, g64, rtol=2e-2, atol=2e-2 * np.abs(g64).max())
+
+
 def test_cfg2_size_properties():
     """BASELINE config 2 (N=8192, D=8, fp64): size-independent properties instead of an O(n^3) oracle run --
     (i) the gradient agrees with central differences of the loss along a random direction,
