@@ -360,9 +360,10 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
 
 // Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
 // panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
-//   panel stream  (handle's high-priority stream)       : Chain(0)            [wait Sa(0)] Chain(1)        [wait Sa(1)] Chain(2) ...
-//   update stream (handle's CU-masked stream)            :   [wait Chain(0)] Sa(0) Sb(0)     [wait Chain(1)] Sa(1) Sb(1) ...
-// Chain(o+1) touches only panel o+1's columns and Sb(o) only columns right of it, so they overlap.  The update
+//   panel stream  (handle's high-priority stream)       : Chain(0) Sa(0) Chain(1) [wait Sb(0)] Sa(1) Chain(2) [wait Sb(1)] Sa(2) ...
+//   update stream (handle's CU-masked stream)            :   [wait Chain(0)] Sb(0)     [wait Chain(1)] Sb(1) ...
+// Sa(o) and Chain(o+1) touch only panel o+1's columns and Sb(o) only columns right of it, so they overlap; Sa(o)
+// follows Sb(o-1), the previous writer of its tiles, so every tile still receives its updates in panel order.  The update
 // stream may not use the last PG_RESERVED_CUS compute units: the chain's small kernels (and the leaf, which needs a
 // whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
 // the caller's stream at the end.
@@ -388,10 +389,6 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     const int split = (Minv && la && ctx->bg && npan >= 4) ? (npan / 2) * NBO : 0;
     for (int o = 0; o < npan; ++o) {
         const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
-        if (la && o > 0) {   // this panel's columns must have received Sa(o-1)
-            if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
-            PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
-        }
         for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
             T* Akk = A + (long)k0 * lda + k0;
             T* inv = invD + (long)(k0 / NB) * NB * NB;
@@ -430,11 +427,11 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.alpha = (T)-1; p.beta = (T)1;
             // few 128x128 tiles with a 1024-deep K loop leave most CUs idle: use 64x64 tiles then (4x the workgroups)
             const long tiles = (long)(p.M / 128) * (p.N / 128);
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
-        }
-        if (la) {
-            if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sa[o]
-            PG_CHECK(hipEventRecord(ev, us));
+            if (la && o > 0) {   // these columns were last written by Sb(o-1)
+                if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
+                PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+            }
+            if ((rc = pg_gemm<T>(ctx, la ? ps : us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         const int m2 = n - o2;
         if (m2 > 0) {  // Sb(o)
@@ -445,6 +442,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
             const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
             if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+        }
+        if (la) {
+            if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]
+            PG_CHECK(hipEventRecord(ev, us));
         }
     }
     if (la) {   // join both streams back onto the caller's stream
