@@ -183,11 +183,22 @@ def main():
         achieved = flops / ms / 1e9 if ms > 0 else 0.0
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,   # filled from the committed PMC passes below
             "kernel": "pg_gemm_kernel<double,...> (MFMA GEMM core, all instantiations) over one evaluation",
             "launches": launches, "avg_launch_ms": ms / max(launches, 1), "flops_per_launch": flops / max(launches, 1),
             "algorithmic_flops_per_eval": float(n) ** 3, "eval_tflops": float(n) ** 3 / (elapsed / args.steps) / 1e12,
         }
+        # HBM-side bytes of the GEMM-core launches: PMC counters cannot be read from inside this process; they come
+        # from separate rocprofv3 --pmc passes over the same evaluation (tools/probe_eval_once.py, tools/pmc_summary.py),
+        # committed under profiles/.  Only valid for the default problem size.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_eval_traffic.json")
+        if n == 16384 and os.path.exists(pmc):
+            with open(pmc) as fh:
+                k = json.load(fh)["kernels"]["gemm_core"]
+            out["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "B per launch (2 x FETCH_SIZE + WRITE_SIZE, %d launches, %.1f GB per evaluation)" % (
+                k["launches"], k["hbm_bytes"] / 1e9)
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_eval_traffic.json"
         # potrf alone and the covariance build, HIP events on torch's current stream (the library's stream)
         exp = model.gpl._device_experts()[0]
         npad = exp.n_pad

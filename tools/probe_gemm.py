@@ -19,3 +19,12 @@ for K in (256, 1024, 4096):
 m = torch.tril(torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g))
 t = ev(lambda: ops.gemm_raw(GEMM_TN, n, n, n, 1.0, m, m, 0.0, c, tri=1, klo=1), 3)
 print(f"lauum n={n}: {t:.3f} ms {n**3/3/t/1e9:.1f} TF/s")
+del m, c
+nu = 8192
+a = torch.randn(nu, nu, device="cuda", dtype=torch.float64, generator=g)
+b = torch.randn(nu, nu, device="cuda", dtype=torch.float64, generator=g)
+cu = torch.zeros(nu, nu, device="cuda", dtype=torch.float64)
+from pygpr_amd._lib import GEMM_NN, GEMM_TT
+for name, var in (("NT", GEMM_NT), ("NN", GEMM_NN), ("TN", GEMM_TN), ("TT", GEMM_TT)):
+    t = ev(lambda: ops.gemm_raw(var, nu, nu, nu, 1.0, a, b, 0.0, cu))
+    print(f"uniform {name} {nu}^3: {t:.3f} ms {2*nu**3/t/1e9:.1f} TF/s", flush=True)
