@@ -371,6 +371,31 @@ def test_fp32_opt_in():
     np.testing.assert_allclose(grad, g_ref, rtol=2e-2, atol=2e-2 * np.abs(g_ref).max())
 
 
+def test_grbcm_fp32_committee(golden):
+    """BASELINE config 5's layout at fixture size: fp32 committee (Matern-5/2 + noise, shared hp) against the fp64
+    oracle -- rtol 1e-3 class."""
+    g = golden("grbcm")
+    p = "g1_"
+    cov = pg.Compose([pg.Matern52(), pg.White_noise()])
+    f32 = lambda a: T(a).float()
+    m = pg.GRBCM(f32(g[p + "xl"]), f32(g[p + "yl"]), f32(g[p + "xg"]), f32(g[p + "yg"]), cov)
+    hp = np.array([1.0, 0.8, 0.8, 0.8, 0.1])
+    m.set_params(T(hp))
+    mu, var = m.predict(f32(g[p + "xs"]), var="diag")
+    assert mu.dtype == torch.float32
+    nc = g[p + "xl"].shape[0]
+    mu_ref, var_ref = orc.grbcm_predict([orc.M52, orc.WN], hp, np.broadcast_to(hp, (nc, hp.size)), g[p + "xl"], g[p + "yl"],
+                                        g[p + "xg"], g[p + "yg"], g[p + "xs"])[:2]
+    np.testing.assert_allclose(N(mu), mu_ref, atol=2e-3)
+    np.testing.assert_allclose(N(var), var_ref, rtol=2e-2, atol=1e-4)
+    loss, grad = pg.GRBCM_MLE(m).loss_and_grad(hp.copy())
+    x, y = orc.grbcm_data(g[p + "xl"], g[p + "yl"], g[p + "xg"], g[p + "yg"])
+    ref = [orc.mle_loss_and_grad([orc.M52, orc.WN], hp, x[c], y[c], "kinv") for c in range(nc)]
+    np.testing.assert_allclose(loss, sum(r[0] for r in ref), rtol=1e-3)
+    gref = sum(r[1] for r in ref)
+    np.testing.assert_allclose(grad, gref, rtol=2e-2, atol=2e-2 * np.abs(gref).max())
+
+
 def test_fp32_tracks_fp64_at_scale():
     """BASELINE config 5's regime at a size with 32 outer panels: the fp32 path against the fp64 HIP path (itself
     pinned against the oracle above) on the same data -- rtol 1e-3 class, sigma_n = 0.1."""
