@@ -152,6 +152,10 @@ int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
  * everything on the caller's stream (default 1). */
 int pg_set_lookahead(pg_handle h, int on);
 
+/* width of pg_potrf's outer column panel: 0 (default) = chosen from n (512 / 1024 / 2048 columns), otherwise a
+ * multiple of 128.  The result does not depend on it beyond rounding; a tuning and test knob. */
+int pg_set_outer_panel(pg_handle h, int columns);
+
 /* GEMM-core profiling for bench.py's roofline leg: events around every MFMA GEMM launch */
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);

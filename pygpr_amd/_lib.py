@@ -58,6 +58,7 @@ _SIGS = {
     "pg_sqdist_argmin": (_i, [_vp, _i, _vp, _l, _i, _vp, _l, _i, _i, _vp, _l, _vp, _vp]),
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_set_lookahead": (_i, [_vp, _i]),
+    "pg_set_outer_panel": (_i, [_vp, _i]),
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
     "pg_leaf_raw": (_i, [_vp, _i, _vp, _l, _vp, _l, _vp, _i, _vp]),

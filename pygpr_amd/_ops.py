@@ -224,6 +224,9 @@ class HipOps:
     def set_lookahead(self, on):
         _lib.check(self.lib.pg_set_lookahead(self.h, int(on)), "pg_set_lookahead")
 
+    def set_outer_panel(self, columns):
+        _lib.check(self.lib.pg_set_outer_panel(self.h, int(columns)), "pg_set_outer_panel")
+
     def leaf_raw(self, a, inv, info, ablate=0):
         self._chk(a, inv, info)
         _lib.check(self.lib.pg_leaf_raw(self.h, _code(a.dtype), _p(a), a.stride(0), _p(inv), inv.stride(0) if inv is not None else 0,

@@ -62,6 +62,11 @@ int pg_create(pg_handle* h) {
     PG_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     PG_CHECK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
     c->lookahead = 1;
+    {
+        const char* e = getenv("PG_NBO");
+        c->nbo = e ? atoi(e) : 0;
+        if (c->nbo < 128 || c->nbo % 128) c->nbo = 0;
+    }
     {   // update stream on all but the last PG_RESERVED_CUS compute units; without it look-ahead stays off
         hipDeviceProp_t prop;
         int dev = 0;
@@ -311,6 +316,13 @@ int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
 int pg_set_lookahead(pg_handle h, int on) {
     NEED(h, "null handle");
     h->lookahead = (on && h->upd) ? 1 : 0;
+    return 0;
+}
+
+int pg_set_outer_panel(pg_handle h, int columns) {
+    NEED(h, "null handle");
+    NEED(columns == 0 || (columns >= 128 && columns % 128 == 0), "outer panel must be 0 (automatic) or a multiple of 128");
+    h->nbo = columns;
     return 0;
 }
 

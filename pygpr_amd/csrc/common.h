@@ -23,6 +23,7 @@ struct pg_ctx {
     hipEvent_t* pool;         // events for cross-stream dependencies, grown on demand
     int npool;
     int lookahead;            // 0 disables the two-stream Cholesky (default 1)
+    int nbo;                  // outer panel of the Cholesky; 0 = chosen from n (pg_set_outer_panel / PG_NBO)
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;
     double prof_ms;

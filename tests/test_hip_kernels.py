@@ -211,8 +211,8 @@ def test_potrf_solves_inverse(ops, n):
 
 @pytest.mark.parametrize("n", [3072, 2816])
 def test_potrf_lookahead_matches_sequential(ops, n):
-    """n = 3072 spans three outer panels (2816: the last one ragged), so the two-stream look-ahead schedule is
-    active; it must give the same factor as the single-stream schedule (same arithmetic, different overlap) and
+    """n = 3072 spans six 512-column outer panels (2816: the last one ragged), so the two-stream look-ahead schedule
+    is active; it must give the same factor as the single-stream schedule (same arithmetic, different overlap) and
     match LAPACK."""
     rng = np.random.default_rng(33)
     a = spd(n, rng)
@@ -229,9 +229,40 @@ def test_potrf_lookahead_matches_sequential(ops, n):
     np.testing.assert_allclose(outs[0], np.linalg.cholesky(a), atol=1e-11)
 
 
+@pytest.mark.parametrize("panel,n", [(1024, 3072), (1024, 3328), (2048, 6144), (256, 1280)])
+def test_potrf_outer_panel_widths(ops, panel, n):
+    """The outer panel is chosen from n (512 / 1024 / 2048); every width, forced through pg_set_outer_panel, must give the
+    LAPACK factor, with and without look-ahead."""
+    rng = np.random.default_rng(panel + n)
+    a = spd(n, rng)
+    chol = np.linalg.cholesky(a)
+    ops.set_outer_panel(panel)
+    try:
+        outs = []
+        for la in (1, 0):
+            ops.set_lookahead(la)
+            ad = dev(a)
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
+            assert int(info.item()) == 0
+            outs.append(np.tril(host(ad)))
+        assert np.array_equal(outs[0], outs[1])
+        np.testing.assert_allclose(outs[0], chol, atol=1e-11)
+        # fused inverse with this width
+        ad = dev(a)
+        ops.set_lookahead(1)
+        minv = ops.zeros(n, n)
+        ops.potrf_trtri(ad, ops.potrf_workspace(n, torch.float64), info, minv)
+        v = rng.standard_normal(n)
+        np.testing.assert_allclose(np.tril(host(minv)) @ (chol @ v), v, atol=1e-9)
+    finally:
+        ops.set_outer_panel(0)
+        ops.set_lookahead(1)
+
+
 @pytest.mark.parametrize("n", [4096, 4352])
 def test_potrf_trtri_fused_matches_separate(ops, n):
-    """n = 4096 has four outer panels (4352: five, the last ragged, trailing part 2304 not a power of two): the fused
+    """n = 4096 has eight outer panels (4352: nine, the last ragged, trailing part 2304 not a power of two): the fused
     call inverts the leading half on the background stream while the Cholesky's tail runs; the factor must equal the
     separate call bit for bit, the inverse too when both routes pair the diagonal blocks the same way."""
     rng = np.random.default_rng(44)

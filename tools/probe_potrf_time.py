@@ -2,7 +2,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from pygpr_amd._ops import get_ops, make_spec
 ops = get_ops()
-for n in (8192, 16384):
+for n in ([int(a) for a in sys.argv[1:]] or [8192, 16384]):
     d = 8
     rng = np.random.default_rng(1234)
     x = torch.from_numpy(rng.random((n, d))).cuda()
