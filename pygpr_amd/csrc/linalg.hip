@@ -163,19 +163,41 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ pa
     out[j] = (T)(a + b * s);
 }
 
-// y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 128-block (lower-triangular M)
+// y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 128-block (lower-triangular M).
+// 16-byte loads, four independent partial sums per lane, and the long rows (bottom of the matrix) launched first.
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ M, long ldm, int n, const T* __restrict__ x,
                                                      T* __restrict__ y) {
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = gridDim.x - 1 - blockIdx.x;
     for (int r = 0; r < 4; ++r) {
-        const int i = blockIdx.x * 16 + wave * 4 + r;
-        if (i >= n) return;
-        const int jend = (i / NB + 1) * NB;
+        const int i = b * 16 + wave * 4 + r;
+        if (i >= n) continue;
+        const int jend = (i / NB + 1) * NB;   // multiple of 128 = 64 lanes x VE (fp64) or 32 lanes x VE (fp32)
         const T* row = M + (long)i * ldm;
-        double s = 0.0;
-        for (int j = lane; j < jend; j += 64) s += (double)row[j] * (double)x[j];
-        s = wave_sum(s);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = lane * VE;
+        for (; j + 3 * 64 * VE < jend; j += 4 * 64 * VE) {
+            const vec_t a0 = *reinterpret_cast<const vec_t*>(row + j), b0 = *reinterpret_cast<const vec_t*>(x + j);
+            const vec_t a1 = *reinterpret_cast<const vec_t*>(row + j + 64 * VE), b1 = *reinterpret_cast<const vec_t*>(x + j + 64 * VE);
+            const vec_t a2 = *reinterpret_cast<const vec_t*>(row + j + 128 * VE), b2 = *reinterpret_cast<const vec_t*>(x + j + 128 * VE);
+            const vec_t a3 = *reinterpret_cast<const vec_t*>(row + j + 192 * VE), b3 = *reinterpret_cast<const vec_t*>(x + j + 192 * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                s0 += (double)a0[e] * (double)b0[e];
+                s1 += (double)a1[e] * (double)b1[e];
+                s2 += (double)a2[e] * (double)b2[e];
+                s3 += (double)a3[e] * (double)b3[e];
+            }
+        }
+        for (; j < jend; j += 64 * VE) {
+            const vec_t a0 = *reinterpret_cast<const vec_t*>(row + j), b0 = *reinterpret_cast<const vec_t*>(x + j);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s0 += (double)a0[e] * (double)b0[e];
+        }
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
         if (lane == 0) y[i] = (T)s;
     }
 }

@@ -316,12 +316,14 @@ def test_potrf_fp32(ops):
 
 
 # --------------------------------------------------------------------------- NLML pieces
-@pytest.mark.parametrize("covs,d", [([orc.SE, orc.WN], 3), ([orc.SE, orc.SE, orc.WN], 8), ([orc.M52, orc.WN], 5),
-                                    ([orc.SE, orc.WN], 16)])
-def test_nlml_value_and_grad(ops, covs, d):
+@pytest.mark.parametrize("covs,d,n", [([orc.SE, orc.WN], 3, 333), ([orc.SE, orc.SE, orc.WN], 8, 333), ([orc.M52, orc.WN], 5, 333),
+                                      ([orc.SE, orc.WN], 16, 333),
+                                      ([orc.SE, orc.WN], 8, 1500),     # 24 tile rows: two strips of column tiles per row
+                                      ([orc.SE, orc.WN], 40, 333),     # the d <= 64 instantiation (> 64 KB of LDS)
+                                      ([orc.WN], 3, 200)])             # pure white noise: only the trace of W
+def test_nlml_value_and_grad(ops, covs, d, n):
     from pygpr_amd._ops import pad_to
 
-    n = 333
     x, y = orc.synth(n, d, seed=d)
     rng = np.random.default_rng(d)
     hp = np.concatenate([0.6 + 0.6 * rng.random(c.nhp(d)) if c.kind != "wn" else np.array([0.1]) for c in covs])

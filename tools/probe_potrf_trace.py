@@ -3,7 +3,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops, make_spec
 ops = get_ops()
-n, d = 16384, 8
+n, d = (int(sys.argv[2]) if len(sys.argv) > 2 else 16384), 8
 rng = np.random.default_rng(1234)
 x = torch.from_numpy(rng.random((n, d))).cuda()
 hp = torch.tensor([1.0] + [1.0] * d + [0.1], dtype=torch.float64).cuda()
