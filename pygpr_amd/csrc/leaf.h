@@ -2,5 +2,5 @@
 #include "common.h"
 // Factor the 128x128 diagonal block A (lower Cholesky, in place) and, when inv != NULL, write its
 // inverse (lower, upper part zero) to inv.  *info (device) receives col0 + j + 1 on a bad pivot.
-// ablate != 0 skips phases (timing diagnostics only: bit 0 factor loop, 1 inverse, 2 doubling levels, 3 diagonal step).
+// ablate != 0 skips phases (timing diagnostics only: bit 0 factor loop, 1 inverse, 3 diagonal step).
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate = 0);

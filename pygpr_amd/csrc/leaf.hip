@@ -9,9 +9,14 @@
 //      tile column), which nothing in A or B depends on.
 //   B. panel solve  P <- P D^-T  by forward substitution, one thread per row (D broadcast from LDS)
 //   C. first tile column of the trailing update  T <- T - P P^T  (next diagonal block + next panel), MFMA
-// The inverse of the whole block then follows by recursive doubling from the eight 16x16 inverses:
-// X21 = -X22 (L21 X11), level by level (16, 32, 64), again MFMA on LDS; the mirrored (upper) block is
-// the scratch for L21 X11.  LDS: S[128][130] + 8 x [16][18] inverses, all in the dynamic region.
+// The inverse X = L^-1 is built inside the same loop by waves that would otherwise idle (block-row forward recurrence on
+// 16x16 tiles, X[p][q] = -D_p^-1 sum_{r=q}^{p-1} L[p][r] X[r][q] with X[q][q] = D_q^-1):
+//   - phase B of micro-panel jb (panel rows x D^-T, one thread per row) takes 16 more threads that run the same
+//     substitution on identity rows: that is Dinv[jb], at no extra time;
+//   - during phase A of micro-panel jb+1 the deferred-update work of waves 1-7 shrinks as jb grows while block row jb of X
+//     grows: they share one work list.  X[p][q] (p > q) lives in the upper tile (q, p) of S, which the factorisation never
+//     touches; after the loop only Dinv[7] and block row 7 are left.
+// LDS: S[128][130] + 8 x [16][18] diagonal inverses, all in the dynamic region.
 #include "leaf.h"
 
 #define NB 128
@@ -70,6 +75,55 @@ __device__ __forceinline__ void lds_tile_mm(T* C, int ldc, const T* A, int lda, 
     for (int r = 0; r < 4; ++r) C[Mfma<T>::row(lane, r) * ldc + fr] = alpha * acc[r] + beta * cin[r];
 }
 
+// One 16x16 tile of the inverse, X[p][q] (p > q), by one wave: W = sum_{r=q}^{p-1} L[p][r] X[r][q], X[p][q] = -Dinv[p] W.
+// X[r][q] for r > q is read from upper tile (q, r); the result goes to upper tile (q, p) (also the scratch for W).
+template <typename T>
+__device__ __forceinline__ void inv_tile(T* S, const T* Dinv, int p, int q, int lane) {
+    typename Mfma<T>::acc_t acc;
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+    const T* Lp = S + (16 * p + fr) * LD;
+    for (int r = q; r < p; ++r) {
+        T a[4], b[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a[kk] = Lp[16 * r + 4 * kk + fk];
+            b[kk] = (r == q) ? Dinv[q * 16 * DLD + (4 * kk + fk) * DLD + fr] : S[(16 * q + 4 * kk + fk) * LD + 16 * r + fr];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(a[kk], b[kk], acc);
+    }
+    T* Wt = S + (16 * q) * LD + 16 * p;            // tile (q, p): W, then X[p][q]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[Mfma<T>::row(lane, r) * LD + fr] = acc[r];
+    T a[4], b[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a[kk] = Dinv[p * 16 * DLD + fr * DLD + 4 * kk + fk];
+        b[kk] = Wt[(4 * kk + fk) * LD + fr];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(a[kk], b[kk], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[Mfma<T>::row(lane, r) * LD + fr] = -acc[r];
+}
+
+// x <- x D^-T for one 16-long row x (forward substitution; D = factored 16x16 diagonal block in LDS, rd = reciprocals of
+// its diagonal).  Panel rows use it for P <- P D^-T; identity rows e_i give column i of D^-1.
+template <typename T>
+__device__ __forceinline__ void row_solve16(T (&x)[16], const T* D, const T* rd) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        T sacc = x[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) sacc -= x[k] * D[c * LD + k];
+        x[c] = sacc * rd[c];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                                       int* __restrict__ info, int col0, int ablate) {
@@ -94,6 +148,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
     __syncthreads();
 
     T* Rd = Dinv + 8 * 16 * DLD + 2;   // [16] reciprocals of the current diagonal block's diagonal (behind the flag)
+    const bool want_inv = inv != nullptr && !(ablate & 2);   // ablate bit 1: no inverse
     for (int jb = 0; jb < ((ablate & 1) ? 0 : NB / 16); ++jb) {   // ablate bit 0: skip the factorisation loop
         const int c0 = jb * 16, r0 = c0 + 16;
         if (wave == 0 && !(ablate & 8)) {   // bit 3: skip the diagonal step
@@ -122,18 +177,24 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
 #pragma unroll
                 for (int c = 0; c < 16; ++c) D[r * LD + c] = (c <= r) ? row[c] : (T)0;
             }
-        } else if (jb > 0) {
-            // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti
+        } else if (wave > 0 && jb > 0) {
+            // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti; then block row
+            // jb - 1 of the inverse (its diagonal inverse was formed during the previous phase B)
             const int pc0 = c0 - 16, pr0 = c0;           // previous panel's columns / first trailing row
             const int pnt = (NB - pr0) / 16;
             const int nrest = pnt * (pnt - 1) / 2;       // pairs (ti, tj): 1 <= tj <= ti <= pnt - 1
-            for (int t = wave - 1; t < nrest; t += NWV - 1) {
-                int u = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (u * (u + 1) / 2 > t) --u;
-                while ((u + 1) * (u + 2) / 2 <= t) ++u;
-                const int ti = u + 1, tj = t - u * (u + 1) / 2 + 1;
-                lds_tile_mm<T, true>(S + (pr0 + ti * 16) * LD + pr0 + tj * 16, LD, S + (pr0 + ti * 16) * LD + pc0, LD,
-                                     S + (pr0 + tj * 16) * LD + pc0, LD, 16, (T)-1, (T)1, lane);
+            const int nx = want_inv ? jb - 1 : 0;        // tiles X[jb-1][q], q = 0 .. jb-2
+            for (int t = wave - 1; t < nrest + nx; t += NWV - 1) {
+                if (t < nrest) {
+                    int u = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                    while (u * (u + 1) / 2 > t) --u;
+                    while ((u + 1) * (u + 2) / 2 <= t) ++u;
+                    const int ti = u + 1, tj = t - u * (u + 1) / 2 + 1;
+                    lds_tile_mm<T, true>(S + (pr0 + ti * 16) * LD + pr0 + tj * 16, LD, S + (pr0 + ti * 16) * LD + pc0, LD,
+                                         S + (pr0 + tj * 16) * LD + pc0, LD, 16, (T)-1, (T)1, lane);
+                } else {
+                    inv_tile<T>(S, Dinv, jb - 1, t - nrest, lane);
+                }
             }
         }
         __syncthreads();
@@ -141,21 +202,24 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
         if (r0 >= NB) break;
         const int nt = (NB - r0) / 16;   // 16-row tiles below the diagonal block
         // ---- B: P <- P D^-T by forward substitution, one thread per row; D and 1/diag are broadcast reads from LDS
+        // the 16 threads after the panel rows run the same substitution on identity rows: row e_i D^-T = column i of D^-1
+        // (on wave 7, which has no panel rows -- NB - r0 <= 112 -- so the two kinds of row never share a wave and diverge)
         if (tid < NB - r0) {
             T* Prow = S + (r0 + tid) * LD + c0;
-            const T* D = S + c0 * LD + c0;
             T x[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = Prow[c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                T sacc = x[c];
-#pragma unroll
-                for (int k = 0; k < c; ++k) sacc -= x[k] * D[c * LD + k];
-                x[c] = sacc * Rd[c];
-            }
+            row_solve16<T>(x, S + c0 * LD + c0, Rd);
 #pragma unroll
             for (int c = 0; c < 16; ++c) Prow[c] = x[c];
+        } else if (wave == NWV - 1 && lane < 16 && want_inv) {
+            T x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = (c == lane) ? (T)1 : (T)0;
+            row_solve16<T>(x, S + c0 * LD + c0, Rd);
+            T* dst = Dinv + jb * 16 * DLD + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c * DLD] = x[c];
         }
         __syncthreads();
         // ---- C (first tile column): next diagonal block and next panel, T <- T - P P^T
@@ -173,63 +237,39 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
         if (k + 1 > i) v[1] = (T)0;
         *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
     }
-    if (inv == nullptr || (ablate & 2)) return;   // bit 1: skip the inverse
-    __syncthreads();
-
-    // ---- inverse, level 0: the eight 16x16 diagonal inverses, one per wave (lane c solves D x = e_c with broadcast
-    // reads of D); then drop them on the diagonal and clear everything above it
-    if (wave < 8 && lane < 16) {
-        const T* D = S + (wave * 16) * LD + wave * 16;
+    if (!want_inv) return;
+    // ---- block rows 0..6 of the inverse are final (last barrier of the loop): their stores go out first and overlap
+    // with what is left to compute, the last diagonal inverse and block row 7
+    auto store_inv_rows = [&](int row_lo, int row_hi) {
+        for (int idx = row_lo * 64 + tid; idx < row_hi * 64; idx += NTH) {
+            const int i = idx >> 6, k = (idx & 63) * 2;
+            const int pb = i >> 4, qb = k >> 4, ii = i & 15;
+            pair_t v = {(T)0, (T)0};
+            if (qb == pb) {
+                const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
+                v[0] = (k <= i) ? Dv[0] : (T)0;
+                v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
+            } else if (qb < pb) {
+                const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);   // X[pb][qb] lives in upper tile (qb, pb)
+                v[0] = Xt[0];
+                v[1] = Xt[1];
+            }
+            *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+        }
+    };
+    store_inv_rows(0, 112);
+    if (tid < 16) {   // Rd still holds block 7's reciprocals
         T x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T sacc = (i == lane) ? (T)1 : (T)0;
+        for (int c = 0; c < 16; ++c) x[c] = (c == tid) ? (T)1 : (T)0;
+        row_solve16<T>(x, S + 112 * LD + 112, Rd);
 #pragma unroll
-            for (int k = 0; k < i; ++k) sacc -= D[i * LD + k] * x[k];
-            x[i] = sacc / D[i * LD + i];
-        }
-        T* Dv = Dinv + wave * 16 * DLD;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Dv[i * DLD + lane] = x[i];
+        for (int c = 0; c < 16; ++c) Dinv[7 * 16 * DLD + c * DLD + tid] = x[c];
     }
     __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += NTH) {
-        const int i = idx >> 7, k = idx & 127;
-        if (k > i) S[i * LD + k] = (T)0;
-        else if ((i >> 4) == (k >> 4)) S[i * LD + k] = Dinv[(i >> 4) * 16 * DLD + (i & 15) * DLD + (k & 15)];
-    }
+    if (wave < 7) inv_tile<T>(S, Dinv, 7, wave, lane);
     __syncthreads();
-
-    // ---- levels s = 16, 32, 64: X21 = -X22 (L21 X11)
-    for (int s = 16; s < ((ablate & 4) ? 0 : NB); s <<= 1) {   // bit 2: skip the doubling levels
-        const int tps = s / 16;
-        const int tiles = (NB / (2 * s)) * tps * tps;
-        for (int t = wave; t < tiles; t += NWV) {
-            const int pr = t / (tps * tps), tt = t % (tps * tps), bi = tt / tps, bj = tt % tps;
-            const int q0 = pr * 2 * s;
-            lds_tile_mm<T, false>(S + (q0 + bi * 16) * LD + q0 + s + bj * 16, LD,      // scratch tile (mirror)
-                                  S + (q0 + s + bi * 16) * LD + q0, LD,                // L21 rows
-                                  S + q0 * LD + q0 + bj * 16, LD, s, (T)1, (T)0, lane);   // X11 cols
-        }
-        __syncthreads();
-        for (int t = wave; t < tiles; t += NWV) {
-            const int pr = t / (tps * tps), tt = t % (tps * tps), bi = tt / tps, bj = tt % tps;
-            const int q0 = pr * 2 * s;
-            lds_tile_mm<T, false>(S + (q0 + s + bi * 16) * LD + q0 + bj * 16, LD,      // X21 tile
-                                  S + (q0 + s + bi * 16) * LD + q0 + s, LD,            // X22 rows
-                                  S + q0 * LD + q0 + s + bj * 16, LD, s, (T)-1, (T)0, lane);   // scratch cols
-        }
-        __syncthreads();
-        for (int idx = tid; idx < (NB / (2 * s)) * s * s; idx += NTH) {
-            const int pr = idx / (s * s), e = idx % (s * s), i = e / s, k = e % s;
-            S[(pr * 2 * s + i) * LD + pr * 2 * s + s + k] = (T)0;
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
-        const int i = idx >> 6, k = (idx & 63) * 2;
-        *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = *reinterpret_cast<const pair_t*>(S + i * LD + k);
-    }
+    store_inv_rows(112, 128);
 }
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
