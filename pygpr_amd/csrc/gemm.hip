@@ -13,10 +13,10 @@
 
 #define BK 16
 
-template <typename T, int R, bool KCONT> struct Stage {
+template <typename T, int R, bool KCONT, int BKT = BK> struct Stage {
     static constexpr int VE = 16 / sizeof(T);
-    static constexpr int NV = (R * BK / VE) / 256;
-    static constexpr int LDS_ELEMS = KCONT ? R * (BK + 2) : BK * (R + 16);
+    static constexpr int NV = (R * BKT / VE) / 256;
+    static constexpr int LDS_ELEMS = KCONT ? R * (BKT + 2) : BKT * (R + 16);
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     typedef T half_t __attribute__((ext_vector_type(VE / 2)));
     vec_t v[NV];
@@ -27,7 +27,7 @@ template <typename T, int R, bool KCONT> struct Stage {
             const int idx = tid + 256 * q;
             const T* p;
             if (KCONT) {
-                const int row = idx / (BK / VE), kv = idx % (BK / VE);
+                const int row = idx / (BKT / VE), kv = idx % (BKT / VE);
                 p = g + (long)(r0 + row) * ld + k0 + kv * VE;
             } else {
                 const int kr = idx / (R / VE), rv = idx % (R / VE);
@@ -41,8 +41,8 @@ template <typename T, int R, bool KCONT> struct Stage {
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + 256 * q;
             if (KCONT) {
-                const int row = idx / (BK / VE), kv = idx % (BK / VE);
-                T* d = s + row * (BK + 2) + kv * VE;   // 8-byte aligned for fp32, 16 for fp64
+                const int row = idx / (BKT / VE), kv = idx % (BKT / VE);
+                T* d = s + row * (BKT + 2) + kv * VE;   // 8-byte aligned for fp32, 16 for fp64
                 half_t lo, hi;
 #pragma unroll
                 for (int e = 0; e < VE / 2; ++e) { lo[e] = v[q][e]; hi[e] = v[q][e + VE / 2]; }
@@ -60,17 +60,19 @@ template <typename T, int R, bool KCONT> struct Stage {
     }
     // fragment element for MFMA lane l: (row r0 + (l&15), k kk*4 + (l>>4))
     static __device__ __forceinline__ T frag(const T* s, int r, int k) {
-        return KCONT ? s[r * (BK + 2) + k] : s[k * (R + 16) + r];
+        return KCONT ? s[r * (BKT + 2) + k] : s[k * (R + 16) + r];
     }
 };
 
-template <typename T, bool TA, bool TB, int BM, int BN, int EPI>
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK>
 __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
-    typedef Stage<T, BM, !TA> SA;   // A: K-contiguous when not transposed
-    typedef Stage<T, BN, TB> SB;    // B: K-contiguous when transposed
+    typedef Stage<T, BM, !TA, BKT> SA;   // A: K-contiguous when not transposed
+    typedef Stage<T, BN, TB, BKT> SB;    // B: K-contiguous when transposed
     typedef typename Mfma<T>::acc_t acc_t;
-    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : 32;   // wave tile rows; 4 waves cover BM x BN
-    constexpr int WTN = (BN == 64) ? 32 : 64;                 // wave tile columns
+    // wave tile; 4 waves cover BM x BN: 128x128 -> 64x64, 64x256 -> 64x64, 64x64 -> 32x32, 64x128 -> 32x64,
+    // 32x64 -> 16x32, 32x128 -> 32x32
+    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN == 64) ? 16 : 32);
+    constexpr int WTN = (BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64;
     constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
     constexpr int WN_ = BN / WTN;                             // waves along N
     static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves must tile the block");
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
 
     SA sa;
     SB sb;
-    const int nk = (kend - kbeg) / BK;
+    const int nk = (kend - kbeg) / BKT;
     if (nk > 0) {
         sa.load(A, p.lda, m0, kbeg, tid);
         sb.load(B, p.ldb, n0, kbeg, tid);
@@ -170,16 +172,16 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const int k0 = kbeg + kt * BK;
+        const int k0 = kbeg + kt * BKT;
         if (kt + 1 < nk) {
-            sa.load(A, p.lda, m0, k0 + BK, tid);
-            sb.load(B, p.ldb, n0, k0 + BK, tid);
+            sa.load(A, p.lda, m0, k0 + BKT, tid);
+            sb.load(B, p.ldb, n0, k0 + BKT, tid);
         }
-        if (k0 + BK > kbw && k0 < kew) {   // wave-uniform
+        if (k0 + BKT > kbw && k0 < kew) {   // wave-uniform
             const T* as = As + cur * SA::LDS_ELEMS;
             const T* bs = Bs + cur * SB::LDS_ELEMS;
 #pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
+            for (int kk = 0; kk < BKT / 4; ++kk) {
                 T a[MIM], bq[MIN];
 #pragma unroll
                 for (int i = 0; i < MIM; ++i) a[i] = SA::frag(as, wm * WTM + i * 16 + fr, kk * 4 + fk);
@@ -233,19 +235,19 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int EPI>
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK>
 static int launch(hipStream_t st, const GemmP<T>& p) {
-    typedef Stage<T, BM, !TA> SA;
-    typedef Stage<T, BN, TB> SB;
+    typedef Stage<T, BM, !TA, BKT> SA;
+    typedef Stage<T, BN, TB, BKT> SB;
     const size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T);
     static bool attr_done = false;
-    auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI>;
+    auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI, BKT>;
     if (!attr_done) {
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (p.M % BM || p.N % BN || p.K % BK || (p.tri && BM != BN)) {
+    if (p.M % BM || p.N % BN || p.K % BKT || (p.tri && BM != BN)) {
         pg_set_error("pg_gemm: shape %d x %d x %d not tile aligned (%d x %d)", p.M, p.N, p.K, BM, BN);
         return -2;
     }
@@ -259,8 +261,9 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
 }
 
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
-    const int BM = (variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128) ? 64 : 128;
-    const int BN = (variant == GEMM_NT_RP) ? 256 : (variant == GEMM_NT_64 ? 64 : 128);
+    const int BM = (variant == GEMM_NT_32x64 || variant == GEMM_NT_32x128) ? 32
+                   : ((variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128) ? 64 : 128);
+    const int BN = (variant == GEMM_NT_RP) ? 256 : ((variant == GEMM_NT_64 || variant == GEMM_NT_32x64) ? 64 : 128);
     const int tm = M / BM, tn = N / BN;
     double f = 0;
     for (int ti = 0; ti < tm; ++ti)
@@ -291,6 +294,8 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         case GEMM_TT_128: rc = launch<T, true, true, 128, 128, 0>(st, p); break;
         case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;
         case GEMM_NT_64x128: rc = launch<T, false, true, 64, 128, 0>(st, p); break;
+        case GEMM_NT_32x64: rc = launch<T, false, true, 32, 64, 0, 32>(st, p); break;
+        case GEMM_NT_32x128: rc = launch<T, false, true, 32, 128, 0, 32>(st, p); break;
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;

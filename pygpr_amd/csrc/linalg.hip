@@ -19,11 +19,11 @@
 #define NB 128      // diagonal block / leaf size; inv_diag holds [n/128][128][128]
 // Outer panel of the Cholesky.  Narrow panels keep the serial chain short (its U products grow with the panel), wide
 // ones make the trailing update deep enough to run at the GEMM core's rate; measured on MI355X (fp64, fused with L^-1):
-// 512 wins up to n = 12288 (-9 % at 8192), 1024 from 14336 to 16384, 2048 from 20480 (-5 % at 32768).
+// 512 wins up to n = 9216 (-4 % at 8192), 1024 from 12288 to 16384, 2048 from 20480 (-5 % at 32768).
 // pg_set_outer_panel (initialised from PG_NBO) overrides.
 static int pg_nbo(const pg_ctx* ctx, int n) {
     if (ctx->nbo) return ctx->nbo;
-    return n <= 12288 ? 512 : (n <= 18432 ? 1024 : 2048);
+    return n <= 10240 ? 512 : (n <= 18432 ? 1024 : 2048);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +422,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 p.M = n - k0; p.N = NB; p.K = k0 - o0;
                 p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
                 p.alpha = (T)-1; p.beta = (T)1;
-                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64, p))) return rc;
+                // fewer than two 64-row workgroups per CU: half the row tile keeps two waves on every SIMD (gemm.h)
+                if ((rc = pg_gemm<T>(ctx, ps, p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64, p))) return rc;
             }
             if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
             const int m = n - k0 - NB;
@@ -430,7 +431,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 GemmP<T> p = gp0<T>(); p.info = info;
                 p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
                 p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
-                if ((rc = pg_gemm<T>(ctx, ps, GEMM_NT_64x128, p))) return rc;
+                if ((rc = pg_gemm<T>(ctx, ps, m <= 12288 ? GEMM_NT_32x128 : GEMM_NT_64x128, p))) return rc;
             }
         }
         if (oend >= n) break;

@@ -79,6 +79,29 @@ def test_gemm_row_panel_inplace_and_tri(ops):
             np.testing.assert_allclose(got[blk], ref[blk] if tj <= ti else c0[blk], atol=1e-11)
 
 
+def test_gemm_skinny_chain_variants(ops):
+    """The Cholesky chain's two products in their 64-row and 32-row tilings: C -= A B^T with a 128-wide C, and the
+    in-place panel solve B <- B inv^T against a lower-triangular 128 x 128 inverse (khi = 2)."""
+    from pygpr_amd._lib import GEMM_NT_32x64, GEMM_NT_32x128, GEMM_NT_64, GEMM_NT_64x128
+
+    rng = np.random.default_rng(21)
+    m, k = 416, 384                      # 13 row tiles of 32: ragged against 64
+    a = rng.standard_normal((m, k))
+    b = rng.standard_normal((128, k))
+    c0 = rng.standard_normal((m, 128))
+    inv = np.tril(rng.standard_normal((128, 128)))
+    for vu, vt, mm in ((GEMM_NT_64, GEMM_NT_64x128, 384), (GEMM_NT_32x64, GEMM_NT_32x128, 416)):
+        c = dev(c0[:mm])
+        ops.gemm_raw(vu, mm, 128, k, -1.0, dev(a[:mm]), dev(b), 1.0, c)
+        np.testing.assert_allclose(host(c), c0[:mm] - a[:mm] @ b.T, atol=1e-11)
+        t = dev(c0[:mm])
+        ops.gemm_raw(vt, mm, 128, 128, 1.0, t, dev(inv), 0.0, t, khi=2)
+        np.testing.assert_allclose(host(t), c0[:mm] @ inv.T, atol=1e-11)
+    cf = dev(c0[:416], torch.float32)
+    ops.gemm_raw(GEMM_NT_32x64, 416, 128, k, -1.0, dev(a, torch.float32), dev(b, torch.float32), 1.0, cf)
+    np.testing.assert_allclose(host(cf), c0 - a @ b.T, atol=2e-3)
+
+
 def test_gemm_triangular_k_ranges(ops):
     from pygpr_amd._lib import GEMM_NN, GEMM_TN
 
