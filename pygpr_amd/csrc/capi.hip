@@ -351,7 +351,7 @@ int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double
     NEED(h && A && B && C, "null pointer");
     NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
              variant == GEMM_TT_128 || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_NT_32x64 ||
-             variant == GEMM_NT_32x128,
+             variant == GEMM_NT_32x128 || variant == GEMM_TT_64,
          "variant not exposed");
     DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),
              gemm_raw_t<float>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream));

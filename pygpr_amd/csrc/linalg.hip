@@ -334,7 +334,9 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
             p.C = M + r0 * ldm + r0 + h; p.ldc = ldm;
             p.klo = 1; p.batch = (int)batch;
             p.sA = stride; p.sC = stride; p.sB = 2 * h * (ldl + 1);
-            if ((rc = pg_gemm<T>(ctx, st, GEMM_TT_128, p))) return rc;
+            // few pairs of small blocks: 64 x 64 tiles give 4x the workgroups, each a quarter as long (h = 256: 42 -> 15 us)
+            const bool small = batch * (h / 128) * (h2 / 128) < 512 && h2 % 64 == 0;
+            if ((rc = pg_gemm<T>(ctx, st, small ? GEMM_TT_64 : GEMM_TT_128, p))) return rc;
             // X21 = -X22 S^T
             p = gp0<T>();
             p.M = (int)h2; p.N = (int)h; p.K = (int)h2;
@@ -343,7 +345,7 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
             p.C = M + (r0 + h) * ldm + r0; p.ldc = ldm;
             p.alpha = (T)-1; p.khi = 1; p.batch = (int)batch;
             p.sA = p.sB = p.sC = stride;
-            if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+            if ((rc = pg_gemm<T>(ctx, st, small ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         if (nfull & 1) rem = rem ? h + rem : h;   // the odd block merges with rem, or becomes the new rem
         h *= 2;
@@ -411,7 +413,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     }
     // fused L^-1: split the diagonal at `split` columns; the leading part is inverted in the background once its
     // columns are final (after the chain of panel split/NBO - 1), together with the first top-level product
-    const int split = (Minv && la && ctx->bg && npan >= 4) ? (npan / 2) * NBO : 0;
+    // (below n = 5120 the cross-stream split costs more than the overlap returns: 3.66 vs 3.79 ms at n = 4096)
+    const int split = (Minv && la && ctx->bg && npan >= 4 && n >= 5120) ? (npan / 2) * NBO : 0;
     for (int o = 0; o < npan; ++o) {
         const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
         for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)

@@ -283,14 +283,17 @@ def test_potrf_outer_panel_widths(ops, panel, n):
         ops.set_lookahead(1)
 
 
-@pytest.mark.parametrize("n", [4096, 4352])
+@pytest.mark.parametrize("n", [8192, 5376])
 def test_potrf_trtri_fused_matches_separate(ops, n):
-    """n = 4096 has eight outer panels (4352: nine, the last ragged, trailing part 2304 not a power of two): the fused
-    call inverts the leading half on the background stream while the Cholesky's tail runs; the factor must equal the
-    separate call bit for bit, the inverse too when both routes pair the diagonal blocks the same way."""
-    rng = np.random.default_rng(44)
-    a = spd(n, rng)
-    ad, bd = dev(a), dev(a)
+    """From n = 5120 the fused call inverts the leading half of the diagonal on the background stream while the
+    Cholesky's tail runs (8192: sixteen 512-column panels; 5376: eleven, the last ragged, trailing part 2816 not a power
+    of two).  The factor must equal the separate call bit for bit, the inverse too when both routes pair the diagonal
+    blocks the same way; and the inverse must undo the factor."""
+    g = torch.Generator(device="cuda").manual_seed(44)
+    r = torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g)
+    a = torch.mm(r, r.T) / n + torch.eye(n, device="cuda", dtype=torch.float64)      # test data only
+    del r
+    ad, bd = a.clone(), a.clone()
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     invd = ops.potrf_workspace(n, torch.float64)
     m1, m2 = ops.zeros(n, n), ops.zeros(n, n)
@@ -299,15 +302,16 @@ def test_potrf_trtri_fused_matches_separate(ops, n):
     invd2 = ops.potrf_workspace(n, torch.float64)
     ops.potrf(bd, invd2, info)
     ops.trtri(bd, invd2, m2)
-    assert np.array_equal(np.tril(host(ad)), np.tril(host(bd)))
-    g1, g2 = np.tril(host(m1)), np.tril(host(m2))
+    l1, l2 = torch.tril(ad), torch.tril(bd)
+    assert torch.equal(l1, l2)
+    g1, g2 = torch.tril(m1), torch.tril(m2)
     if n & (n - 1) == 0:     # power of two: both routes pair the diagonal blocks identically
-        assert np.array_equal(g1, g2)
+        assert torch.equal(g1, g2)
     else:                    # the split pairs them differently: same inverse, different rounding order
-        np.testing.assert_allclose(g1, g2, rtol=0, atol=1e-12 * np.abs(g2).max())
-    chol = np.linalg.cholesky(a)
-    v = rng.standard_normal(n)
-    np.testing.assert_allclose(g1 @ (chol @ v), v, atol=1e-9)
+        assert float((g1 - g2).abs().max()) <= 1e-12 * float(g2.abs().max())
+    v = torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+    assert float((g1 @ (l1 @ v) - v).abs().max()) <= 1e-9                          # L^-1 (L v) = v
+    assert float((l1 @ (l1.T @ v) - a @ v).abs().max()) <= 1e-9 * float((a @ v).abs().max())   # L L^T = A
 
 
 def test_potrf_not_positive_definite_reports_minor(ops):
