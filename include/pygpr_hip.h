@@ -76,7 +76,9 @@ int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_d
                    void* stream);
 
 /* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
- * work: 2 n elements. */
+ * work: pg_potrs_vec_worksize(dtype, n) elements (2 n below n = 2048; above, also the 1024-wide diagonal block
+ * inverses the blocked sweeps multiply with). */
+long pg_potrs_vec_worksize(int dtype, int n);
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
                  void* work, void* stream);
 

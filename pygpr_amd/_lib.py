@@ -40,6 +40,7 @@ _SIGS = {
     "pg_potrf_worksize": (_l, [_i, _i]),
     "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_potrf_trtri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp]),
+    "pg_potrs_vec_worksize": (_l, [_i, _i]),
     "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "pg_trtri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
     "pg_lauum": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _vp]),

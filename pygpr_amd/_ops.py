@@ -108,7 +108,7 @@ class HipOps:
 
     def potrs_vec(self, chol, invd, y, x, work=None):
         if work is None:
-            work = self.empty(2 * chol.shape[0], dtype=chol.dtype)
+            work = self.empty(self.lib.pg_potrs_vec_worksize(_code(chol.dtype), chol.shape[0]), dtype=chol.dtype)
         self._chk(chol, invd, y, x, work)
         _lib.check(self.lib.pg_potrs_vec(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
                                          _p(y), _p(x), _p(work), self._st()), "pg_potrs_vec")

@@ -169,6 +169,8 @@ int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_d
              pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info, (float*)Minv, ldm));
 }
 
+long pg_potrs_vec_worksize(int dtype, int n) { (void)dtype; return pg_potrs_vec_worksize_impl(n); }
+
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
                  void* work, void* stream) {
     NEED(h && L && inv_diag && y && x && work, "null pointer");

@@ -152,15 +152,43 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T* __restrict
     part[(long)rc * ldp + j] = (T)s;
 }
 
-// out[j] = a + b * sum_{rc >= rc0(j)} part[rc][j]
+// out[j] = a + b * sum_{rc >= rc0(j)} part[rc][j]   (acc: out[j] += b * sum)
 template <typename T>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ part, long ldp, int nrc, int cols,
-                                                        T* __restrict__ out, int tri, double a, double b) {
+                                                        T* __restrict__ out, int tri, double a, double b, int acc) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cols) return;
     double s = 0.0;
     for (int rc = tri ? j / 256 : 0; rc < nrc; ++rc) s += (double)part[(long)rc * ldp + j];
-    out[j] = (T)(a + b * s);
+    out[j] = (T)((acc ? (double)out[j] : a) + b * s);
+}
+
+// y[i] -= sum_{j < cols} A[i][j] x[j], wave per row (cols a multiple of 256), 16-byte loads
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_n_sub_kernel(const T* __restrict__ A, long lda, int rows, int cols,
+                                                         const T* __restrict__ x, T* __restrict__ y) {
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = 0; r < 4; ++r) {
+        const int i = blockIdx.x * 16 + wave * 4 + r;
+        if (i >= rows) continue;
+        const T* row = A + (long)i * lda;
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = lane * VE; j < cols; j += 2 * 64 * VE) {
+            const vec_t a0 = *reinterpret_cast<const vec_t*>(row + j), b0 = *reinterpret_cast<const vec_t*>(x + j);
+            const bool two = j + 64 * VE < cols;
+            const vec_t a1 = two ? *reinterpret_cast<const vec_t*>(row + j + 64 * VE) : a0;
+            const vec_t b1 = two ? *reinterpret_cast<const vec_t*>(x + j + 64 * VE) : b0;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                s0 += (double)a0[e] * (double)b0[e];
+                if (two) s1 += (double)a1[e] * (double)b1[e];
+            }
+        }
+        const double s = wave_sum(s0 + s1);
+        if (lane == 0) y[i] = (T)((double)y[i] - s);
+    }
 }
 
 // y[i] = sum_{j < jend(i)} M[i][j] x[j], wave per row; jend = end of row i's 128-block (lower-triangular M).
@@ -309,7 +337,7 @@ template <typename T> static GemmP<T> gp0() {
 long pg_potrf_worksize_impl(int n) { return (long)n * NB; }
 
 template <typename T>
-int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm) {
+int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 8), dim3(256), 0, st, invD, M, ldm);
     LAUNCH_CHECK();
@@ -319,6 +347,7 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
     for (;;) {
         const long nfull = (n - rem) / h;
         if (nfull + (rem ? 1 : 0) <= 1) break;
+        if (hmax && h >= hmax) break;   // block-diagonal inverse only: blocks of hmax (and a smaller last one)
         const long npair = nfull / 2;
         for (int pass = 0; pass < 2; ++pass) {
             // pass 0: the npair full pairs as one batch; pass 1: the trailing (h, rem) pair if there is one
@@ -501,19 +530,53 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     return 0;
 }
 
+// L L^T x = y for one right-hand side.  Small n: one fused step per 128 columns.  From n = 2048: blocks of HB = 1024
+// columns against their inverses -- the recursive doubling of pg_trtri stopped at HB, stored as the diagonal blocks of a
+// virtual matrix with leading dimension HB (block b at b HB (HB + 1): the blocks do not overlap) -- so a sweep is
+// 2-4 launches per 1024 columns instead of one per 128 (n = 8192: 3.7 -> 0.7 ms).
+#define HB 1024
+long pg_potrs_vec_worksize_impl(int n) { return n < 2 * HB ? 2L * n : (long)n * (2 + (HB + 1) + 4); }
+
 template <typename T>
-int pg_potrs_vec_t(pg_ctx*, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work) {
+int pg_potrs_vec_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrs_vec: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     T* w = work;          // running right-hand side of the forward sweep
     T* z = work + n;      // forward result / running right-hand side of the backward sweep
     PG_CHECK(hipMemcpyAsync(w, y, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st));
-    const int nb = n / NB;
-    for (int b = 0; b < nb; ++b)      // L z = y
-        hipLaunchKernelGGL(trsv_fwd_step_kernel<T>, dim3(std::max(1, (n - (b + 1) * NB) / 64)), dim3(256), 0, st, L, ldl,
-                           invD + (long)b * NB * NB, b, n, w, z);
-    for (int b = nb - 1; b >= 0; --b) // L^T a = z
-        hipLaunchKernelGGL(trsv_bwd_step_kernel<T>, dim3(std::max(1, (b * NB + 255) / 256)), dim3(256), 0, st, L, ldl,
-                           invD + (long)b * NB * NB, b, z, x);
+    if (n < 2 * HB) {
+        const int nb = n / NB;
+        for (int b = 0; b < nb; ++b)      // L z = y
+            hipLaunchKernelGGL(trsv_fwd_step_kernel<T>, dim3(std::max(1, (n - (b + 1) * NB) / 64)), dim3(256), 0, st, L, ldl,
+                               invD + (long)b * NB * NB, b, n, w, z);
+        for (int b = nb - 1; b >= 0; --b) // L^T a = z
+            hipLaunchKernelGGL(trsv_bwd_step_kernel<T>, dim3(std::max(1, (b * NB + 255) / 256)), dim3(256), 0, st, L, ldl,
+                               invD + (long)b * NB * NB, b, z, x);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    T* W = work + 2L * n;                 // block inverses, leading dimension HB
+    T* part = W + (long)n * (HB + 1);     // [4][n] partial sums of the transposed products
+    int rc;
+    if ((rc = pg_trtri_t<T>(ctx, st, n, L, ldl, invD, W, HB, HB))) return rc;
+    for (int o = 0; o < n; o += HB) {     // L z = y
+        const int s = std::min(HB, n - o), below = n - o - s;
+        hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((s + 15) / 16), dim3(256), 0, st, W + (long)o * (HB + 1), (long)HB, s, w + o, z + o);
+        if (below > 0)
+            hipLaunchKernelGGL(gemv_n_sub_kernel<T>, dim3((below + 15) / 16), dim3(256), 0, st, L + (long)(o + s) * ldl + o, ldl,
+                               below, s, z + o, w + o + s);
+    }
+    const int last = ((n - 1) / HB) * HB;
+    for (int o = last; o >= 0; o -= HB) { // L^T x = z
+        const int s = std::min(HB, n - o);
+        hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(s / 256, s / 256), dim3(256), 0, st, W + (long)o * (HB + 1), (long)HB,
+                           z + o, part, (long)n, 1);
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(s / 256), dim3(256), 0, st, part, (long)n, s / 256, s, x + o, 1, 0.0, 1.0, 0);
+        if (o > 0) {                      // z[0:o] -= L[o:o+s, 0:o]^T x[o:o+s]
+            hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(o / 256, s / 256), dim3(256), 0, st, L + (long)o * ldl, ldl, x + o,
+                               part, (long)n, 0);
+            hipLaunchKernelGGL(colreduce_kernel<T>, dim3(o / 256), dim3(256), 0, st, part, (long)n, s / 256, o, z, 0, 0.0, -1.0, 1);
+        }
+    }
     LAUNCH_CHECK();
     return 0;
 }
@@ -534,7 +597,7 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
         hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((n + 15) / 16), dim3(256), 0, st, M, ldm, n, x, y);
     } else {
         hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(n / 256, n / 256), dim3(256), 0, st, M, ldm, x, work, (long)n, 1);
-        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256), dim3(256), 0, st, work, (long)n, n / 256, n, y, 1, 0.0, 1.0);
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256), dim3(256), 0, st, work, (long)n, n / 256, n, y, 1, 0.0, 1.0, 0);
     }
     LAUNCH_CHECK();
     return 0;
@@ -552,7 +615,7 @@ int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, 
                         const T* alpha, T* mean, T* q, double kss, T* work) {
     if (n % PG_PAD || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
     hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(m / 256, n / 256), dim3(256), 0, st, Ks, ldks, alpha, work, (long)m, 0);
-    hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 256, m, mean, 0, 0.0, 1.0);
+    hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 256, m, mean, 0, 0.0, 1.0, 0);
     LAUNCH_CHECK();
     if (q) {
         GemmP<T> p = gp0<T>();
@@ -560,7 +623,7 @@ int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, 
         p.part = work; p.ldp = m;
         int rc = pg_gemm<T>(ctx, st, GEMM_NN_128_SS, p);
         if (rc) return rc;
-        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0, kss, -1.0);
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0, kss, -1.0, 0);
         LAUNCH_CHECK();
     }
     return 0;
@@ -629,7 +692,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 #define INST(T)                                                                                                        \
     template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long);                               \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
-    template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long);                         \
+    template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int);                         \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \

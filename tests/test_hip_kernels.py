@@ -314,6 +314,32 @@ def test_potrf_trtri_fused_matches_separate(ops, n):
     assert float((l1 @ (l1.T @ v) - a @ v).abs().max()) <= 1e-9 * float((a @ v).abs().max())   # L L^T = A
 
 
+@pytest.mark.parametrize("n", [1792, 2304, 3072, 4864])
+def test_potrs_vec_blocked_sweeps(ops, n):
+    """x = A^-1 y from the factor.  Below n = 2048 one fused step per 128 columns; above, sweeps over 1024-wide blocks
+    against their inverses (2304 = two blocks + a 256 remainder, 4864 = four + 768)."""
+    rng = np.random.default_rng(n)
+    a = spd(n, rng)
+    y = rng.standard_normal(n)
+    ad = dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd = ops.potrf_workspace(n, torch.float64)
+    ops.potrf(ad, invd, info)
+    assert int(info.item()) == 0
+    x = ops.empty(n)
+    yd = dev(y)
+    ops.potrs_vec(ad, invd, yd, x)
+    assert torch.equal(yd, dev(y))                        # the right-hand side is not modified
+    ref = np.linalg.solve(a, y)
+    np.testing.assert_allclose(host(x), ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    a32 = dev(a, torch.float32)
+    invd32 = ops.potrf_workspace(n, torch.float32)
+    ops.potrf(a32, invd32, info)
+    x32 = ops.empty(n, dtype=torch.float32)
+    ops.potrs_vec(a32, invd32, dev(y, torch.float32), x32)
+    np.testing.assert_allclose(host(x32), ref, rtol=0, atol=5e-4 * np.abs(ref).max())
+
+
 def test_potrf_not_positive_definite_reports_minor(ops):
     rng = np.random.default_rng(4)
     n = 512
