@@ -340,6 +340,23 @@ def test_potrs_vec_blocked_sweeps(ops, n):
     np.testing.assert_allclose(host(x32), ref, rtol=0, atol=5e-4 * np.abs(ref).max())
 
 
+def test_bad_arguments_are_refused_with_a_message(ops):
+    """Error convention of the C ABI: a negative status and a text from pg_last_error, nothing launched."""
+    from pygpr_amd import _lib
+
+    n = 300                                   # not a multiple of 256
+    a = ops.zeros(n, n)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 256"):
+        ops.potrf(a, ops.potrf_workspace(512, torch.float64), info)
+    with pytest.raises(RuntimeError, match="not tile aligned"):
+        ops.gemm_raw(_lib.GEMM_NT, 200, 128, 64, 1.0, ops.zeros(200, 64), ops.zeros(128, 64), 0.0, ops.zeros(200, 128))
+    with pytest.raises(RuntimeError, match="outer panel"):
+        ops.set_outer_panel(100)
+    assert _lib.load().pg_potrf(None, 0, 256, None, 256, None, None, None) < 0      # null handle / pointers
+    assert b"null" in _lib.load().pg_last_error()
+
+
 def test_potrf_not_positive_definite_reports_minor(ops):
     rng = np.random.default_rng(4)
     n = 512
