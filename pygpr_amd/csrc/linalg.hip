@@ -499,7 +499,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.C = A + (long)o2 * lda + o2; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
             const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            // (threshold swept 512 / 1024 / 2048: 2048 is 2 % faster at n = 8192 and neutral at 16384)
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 2048 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         if (la) {
             if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]
