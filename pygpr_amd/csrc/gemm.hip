@@ -1,13 +1,16 @@
 // MFMA GEMM core (see gemm.h).  gfx950 only.
 //
-// Block tile BM x BN (128x128, or 64x256 for the in-place row-panel solve), BK = 16, 256 threads =
-// 4 waves, each wave owns a 64x64 sub-tile = 4x4 MFMA tiles of 16x16 (16 accumulators: 128 VGPRs in
-// fp64).  Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile);
-// LDS rows are padded so that the fragment read `lane -> (row l&15, k l>>4)` is bank-conflict free:
-//   K-contiguous operand : LDS [R][BK+2]   (row stride 18 elements == 2 mod 32)
-//   M/N-contiguous one   : LDS [BK][R+16]  (row stride == 16 mod 32)
-// One 16x16x4 fp64 MFMA is 2048 flop in 64 cycles per SIMD (78.6 TFLOP/s chip peak), so a K tile is
-// 4096 MFMA cycles per wave against 8 ds_read_b64 per k-step: the loop is MFMA-bound by construction.
+// Block tile BM x BN, K tile BKT, 256 threads = 4 waves, each wave owning a sub-tile of 16x16 MFMA tiles:
+//   128x128 (wave 64x64: 16 accumulators = 128 VGPRs in fp64) -- the throughput tile of every large product;
+//   64x256 and 64x128 (in-place panel solves: one workgroup owns full rows), 64x64 (4x the workgroups for launches with
+//   few large tiles); 32x64 and 32x128 with BKT = 32 (the Cholesky chain's skinny products: two waves per SIMD even when
+//   only one 64-row workgroup per CU exists).
+// Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile); LDS rows are padded so that the
+// fragment read `lane -> (row l&15, k l>>4)` is bank-conflict free:
+//   K-contiguous operand : LDS [R][BKT+2]   (row stride 18 elements == 2 mod 32)
+//   M/N-contiguous one   : LDS [BKT][R+16]  (row stride == 16 mod 32)
+// One 16x16x4 fp64 MFMA is 2048 flop in 64 cycles per SIMD (78.6 TFLOP/s chip peak), so a 16-deep K tile of the 128x128
+// block is 4096 MFMA cycles per wave against 8 ds_read_b64 per k-step: the loop is MFMA-bound by construction.
 #include "gemm.h"
 #include <cstdlib>
 
