@@ -91,6 +91,14 @@ int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void*
  * cholesky_solve(dkrn, L). */
 int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Kinv, long ldk, void* stream);
 
+/* K^-1 (lower triangle) from the factor in one call = pg_trtri followed by pg_lauum (LAPACK's potri; SURVEY 8b lists it
+ * under that name).  work: n x n elements (receives L^-1); Kinv may alias L. */
+int pg_potri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Kinv, long ldk,
+             void* work, void* stream);
+
+/* out[0] = log det K = 2 sum_i log L_ii over the first n (real) rows: the second term of loss.py:47-49 on its own */
+int pg_logdet(pg_handle h, int dtype, int n, const void* L, long ldl, double* out, void* stream);
+
 /* y = op(Minv) x for the lower-triangular Minv (trans: 0 = Minv x, 1 = Minv^T x); work: n/256*n elems */
 int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y,
             void* work, void* stream);

@@ -44,6 +44,8 @@ _SIGS = {
     "pg_potrs_vec": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "pg_trtri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
     "pg_lauum": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "pg_potri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
+    "pg_logdet": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp]),
     "pg_trmv": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp]),
     "pg_nlml_value": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
     "pg_nlml_grad_worksize": (_l, [_i, _i]),

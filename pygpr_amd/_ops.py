@@ -113,6 +113,19 @@ class HipOps:
         _lib.check(self.lib.pg_potrs_vec(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
                                          _p(y), _p(x), _p(work), self._st()), "pg_potrs_vec")
 
+    def potri(self, chol, invd, kinv, work=None):
+        """kinv(lower) = K^-1 from the factor (pg_trtri + pg_lauum in one call)."""
+        n = chol.shape[0]
+        if work is None:
+            work = self.empty(n, n, dtype=chol.dtype)
+        self._chk(chol, invd, kinv, work)
+        _lib.check(self.lib.pg_potri(self.h, _code(chol.dtype), n, _p(chol), chol.stride(0), _p(invd), _p(kinv), kinv.stride(0),
+                                     _p(work), self._st()), "pg_potri")
+
+    def logdet(self, chol, n, out):
+        self._chk(chol, out)
+        _lib.check(self.lib.pg_logdet(self.h, _code(chol.dtype), int(n), _p(chol), chol.stride(0), _p(out), self._st()), "pg_logdet")
+
     def trtri(self, chol, invd, minv):
         self._chk(chol, invd, minv)
         _lib.check(self.lib.pg_trtri(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),

@@ -197,6 +197,23 @@ int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Ki
              pg_lauum_t<float>(h, ST(stream), n, (const float*)Minv, ldm, (float*)Kinv, ldk));
 }
 
+int pg_potri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Kinv, long ldk, void* work,
+             void* stream) {
+    NEED(h && L && inv_diag && Kinv && work, "null pointer");
+    NEED(work != L && work != Kinv, "pg_potri: work must not alias L or Kinv");
+    NEED(ldl >= n && ldk >= n, "leading dimension < n");
+    int rc = pg_trtri(h, dtype, n, L, ldl, inv_diag, work, (long)n, stream);
+    if (rc) return rc;
+    return pg_lauum(h, dtype, n, work, (long)n, Kinv, ldk, stream);
+}
+
+int pg_logdet(pg_handle h, int dtype, int n, const void* L, long ldl, double* out, void* stream) {
+    NEED(h && L && out, "null pointer");
+    NEED(n > 0 && ldl >= n, "bad size");
+    DISPATCH(dtype, pg_logdet_t<double>(ST(stream), n, (const double*)L, ldl, out),
+             pg_logdet_t<float>(ST(stream), n, (const float*)L, ldl, out));
+}
+
 int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y, void* work,
             void* stream) {
     NEED(h && Minv && x && y, "null pointer");

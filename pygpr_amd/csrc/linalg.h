@@ -5,6 +5,7 @@ template <typename T> int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda
 template <typename T> int pg_potrs_vec_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work);
 template <typename T> int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0);
 long pg_potrs_vec_worksize_impl(int n);
+template <typename T> int pg_logdet_t(hipStream_t, int n, const T* L, long ldl, double* out);
 template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);
 template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work);
 template <typename T> int pg_nlml_value_t(hipStream_t, int n, const T* L, long ldl, const T* y, const T* alpha, double* out);

@@ -231,6 +231,18 @@ __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ M, lo
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ L, long ldl, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += 2.0 * log((double)L[(long)i * ldl + i]);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void nlml_value_kernel(const T* __restrict__ L, long ldl, const T* __restrict__ y,
                                                          const T* __restrict__ alpha, int n, double* __restrict__ out) {
     __shared__ double red[4];
@@ -604,6 +616,12 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
     return 0;
 }
 
+template <typename T> int pg_logdet_t(hipStream_t st, int n, const T* L, long ldl, double* out) {
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, n, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 int pg_nlml_value_t(hipStream_t st, int n, const T* L, long ldl, const T* y, const T* alpha, double* out) {
     hipLaunchKernelGGL(nlml_value_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, y, alpha, n, out);
@@ -695,6 +713,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int);                         \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
+    template int pg_logdet_t<T>(hipStream_t, int, const T*, long, double*);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \

@@ -357,6 +357,25 @@ def test_bad_arguments_are_refused_with_a_message(ops):
     assert b"null" in _lib.load().pg_last_error()
 
 
+def test_potri_and_logdet(ops):
+    """pg_potri = K^-1 from the factor in one call (may overwrite the factor); pg_logdet = 2 sum log L_ii over the real rows."""
+    rng = np.random.default_rng(71)
+    n = 768
+    a = spd(n, rng)
+    ad = dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd = ops.potrf_workspace(n, torch.float64)
+    ops.potrf(ad, invd, info)
+    out = ops.zeros(1)
+    ops.logdet(ad, n, out)
+    np.testing.assert_allclose(float(out[0]), np.linalg.slogdet(a)[1], rtol=1e-12)
+    ops.logdet(ad, 500, out)                                   # leading 500 rows only (padding excluded by the caller)
+    np.testing.assert_allclose(float(out[0]), 2.0 * np.log(np.diag(np.linalg.cholesky(a))[:500]).sum(), rtol=1e-12)
+    ops.potri(ad, invd, ad)                                    # in place over the factor
+    ref = np.linalg.inv(a)
+    np.testing.assert_allclose(np.tril(host(ad)), np.tril(ref), rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
 def test_potrf_not_positive_definite_reports_minor(ops):
     rng = np.random.default_rng(4)
     n = 512
