@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): NLML+gradient evaluations/sec at N=16384, D=8, RBF + white noise, fp64.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a bare shell: bench.py starts its own N ranks (a child `python -m torch.distributed.run`, spawned before
+anything touches the GPU) and relays rank 0's JSON line; under a launcher that already set WORLD_SIZE (the driver's
+`python -m torch.distributed.run ... bench.py --gpus N`) it is simply one of the ranks.
 
 One "step" = every rank evaluates `loss_and_grad` (PyGPR/loss.py:92-128) once for ITS expert -- covariance
 build, Cholesky, L^-1, alpha, K^-1, fused gradient contraction at n = 16384, d = 8 -- followed, for N > 1, by
-the shared-hyper-parameter all-reduce(sum) of [1 + nhp] doubles over RCCL (grBCM co-training, GRBCM_MLE).
+the shared-hyper-parameter all-reduce(sum) of [1 + nhp (+ status)] doubles over RCCL (grBCM co-training, GRBCM_MLE).
 At N = 1 that is exactly one exact-GP NLML+grad evaluation.  value = N * K / t (weak scaling, whole job).
 
 Extra objects on the same JSON line:
   roofline      the MFMA GEMM core (all instantiations of pg_gemm_kernel) over one evaluation: algorithmic
                 flop of its launches / summed launch durations measured with HIP events inside the library
-                (pg_profile), against the fp64 matrix peak; plus potrf alone and the covariance build (HBM)
-  cpu_baseline_as_written  the reference's algorithm as written (dK stack + batched cholesky_solve), N=4096, n^3-scaled
+                (pg_profile; single-stream profile mode), against the fp64 matrix peak; `frac_end_to_end` is
+                n^3 / ms_per_step / peak for the headline (multi-stream) schedule
+  dist          backend, world size, the all-gathered rank list and the [1 + nhp] all-reduce latency (N > 1)
+  nlml_check    the evaluation's NLML against the committed fp64 value for the default seed/size (asserted)
+  cholesky, roofline_kernel_build, cfg2_fit_predict, cfg5_cotrain, grbcm_predict   secondary legs (N = 1: all of them)
   cpu_baseline  the CPU oracle's lean K^-1-route evaluation (oracle/pygpr_oracle.py, torch CPU + LAPACK) timed
-                on this host's cores at a bounded size and n^3-scaled to N = 16384
-  grbcm_predict BASELINE config 4 (8 experts x (1024 + 8192) points, D = 16, 65536 test points): committee
-                predictions/sec, experts sharded over the ranks, one [3, m] all-reduce per test batch
+                on this host's cores: min of 2 at N = 8192 and ONE measured evaluation at the full N = 16384
+                (`value`), on the same data as the GPU's -- the oracle's NLML/gradient are compared with the GPU's
+  cpu_baseline_as_written  the reference's algorithm as written (dK stack + batched cholesky_solve), N=4096, n^3-scaled
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk / SIMD, 2.4 GHz)
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 matrix (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+# NLML of rank 0's expert at the default size and seeds (n=16384 = 1024 global [seed 99] + 15360 own [seed 1234], d=8,
+# hp sigma=1 l=1 sigma_n=0.1).  Produced by the HIP path in round 1 (BENCH_r01.json) and confirmed by the CPU oracle's
+# full-size evaluation in round 2 (profiles/r02_fullsize_oracle_check.json).
+EXPECTED_NLML = {(16384, 8, 1024): -12646.821869277313}
+NLML_RTOL = 1e-9
 
 
 def synth_expert(n, d, seed):
@@ -42,24 +58,56 @@ def synth_expert(n, d, seed):
     return x, y
 
 
-def cpu_baseline(n_full, d, n_cpu):
-    """Oracle (kind = "port"), lean K^-1 route, all host cores, n^3-scaled to n_full."""
+def default_hp(d):
+    return np.concatenate([[1.0], np.ones(d), [0.1]])            # sigma, l_1..l_d, sigma_n
+
+
+def cpu_baseline(x_full, y_full, hp, n_small, gpu_loss, gpu_grad, full_size):
+    """Oracle (kind = "port"), lean K^-1 route, all host cores: min of 2 at n_small, and one measured evaluation on
+    the GPU's own data at full size, whose NLML / gradient are compared with the GPU's."""
     from oracle import pygpr_oracle as orc
 
-    x, y = synth_expert(n_cpu, d, 1234)
-    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
-    orc.mle_loss_and_grad_lean(hp, x[:512], y[:512])          # warm LAPACK threads
-    t0 = time.perf_counter()
-    orc.mle_loss_and_grad_lean(hp, x, y)
-    t = time.perf_counter() - t0
-    scale = (n_full / n_cpu) ** 3
+    n_full, d = x_full.shape
     cores = torch.get_num_threads()          # intra-op threads the baseline actually used
-    return {
-        "value": 1.0 / (t * scale), "unit": "evals/s", "cores": cores, "kind": "port",
-        "sample": "1 lean K^-1-route NLML+grad eval (oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK potrf + potri, "
-                  "%d intra-op threads) at N=%d D=%d took %.2f s; n^3-scaled x%.0f to N=%d" % (cores, n_cpu, d, t, scale, n_full),
-        "seconds_measured": t,
+    orc.mle_loss_and_grad_lean(hp, x_full[:512], y_full[:512])          # warm LAPACK threads
+    xs, ys = synth_expert(n_small, d, 1234)
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        orc.mle_loss_and_grad_lean(hp, xs, ys)
+        ts.append(time.perf_counter() - t0)
+    t_small = min(ts)
+    scale = (n_full / n_small) ** 3
+    out = {
+        "unit": "evals/s", "cores": cores, "kind": "port",
+        "small_sample": {"n": n_small, "seconds_min_of_2": t_small, "seconds_all": ts,
+                         "extrapolated_evals_per_s_at_full_n": 1.0 / (t_small * scale)},
     }
+    if full_size:
+        t0 = time.perf_counter()
+        l_ref, g_ref = orc.mle_loss_and_grad_lean(hp, x_full, y_full)
+        t_full = time.perf_counter() - t0
+        out["value"] = 1.0 / t_full
+        out["seconds_measured"] = t_full
+        out["sample"] = ("ONE measured lean K^-1-route NLML+grad evaluation at the full N=%d D=%d on the GPU's own data "
+                         "(oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK potrf + potri, %d intra-op threads): %.1f s; "
+                         "beside it min of 2 at N=%d: %.2f s (x%.0f n^3-extrapolated: %.1f s)"
+                         % (n_full, d, cores, t_full, n_small, t_small, scale, t_small * scale))
+        out["parity_at_full_size"] = {
+            "oracle_nlml": float(l_ref), "gpu_nlml": float(gpu_loss),
+            "nlml_rel_err": abs(float(gpu_loss) - float(l_ref)) / abs(float(l_ref)),
+            "grad_rel_err_inf": float(np.abs(np.asarray(gpu_grad) - g_ref).max() / np.abs(g_ref).max()),
+            "tolerance": "NLML rtol 1e-9, gradient 1e-7 of |g|inf (sigma_n = 0.1 class, SURVEY 8c)",
+        }
+        assert out["parity_at_full_size"]["nlml_rel_err"] < 1e-9, out["parity_at_full_size"]
+        assert out["parity_at_full_size"]["grad_rel_err_inf"] < 1e-7, out["parity_at_full_size"]
+    else:
+        out["value"] = 1.0 / (t_small * scale)
+        out["seconds_measured"] = t_small
+        out["sample"] = ("min of 2 lean K^-1-route NLML+grad evaluations (oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK "
+                         "potrf + potri, %d intra-op threads) at N=%d D=%d: %.2f s; n^3-scaled x%.0f to N=%d (extrapolated)"
+                         % (cores, n_small, d, t_small, scale, n_full))
+    return out
 
 
 def cpu_baseline_as_written(n_full, d, n_cpu):
@@ -68,7 +116,7 @@ def cpu_baseline_as_written(n_full, d, n_cpu):
     from oracle import pygpr_oracle as orc
 
     x, y = synth_expert(n_cpu, d, 1234)
-    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
+    hp = default_hp(d)
     t0 = time.perf_counter()
     orc.mle_loss_and_grad_as_written(hp, x, y)
     t = time.perf_counter() - t0
@@ -83,6 +131,20 @@ def cpu_baseline_as_written(n_full, d, n_cpu):
     }
 
 
+def launch_ranks(n):
+    """`--gpus N` from a bare shell: start N fresh rank processes and relay their output.  Nothing in this process has
+    touched the GPU yet (importing torch and counting devices do not), and it never execs: the launcher is a child."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,22 +153,34 @@ def main():
     ap.add_argument("--n", type=int, default=16384, help="points per expert (BASELINE: 16384)")
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--ng", type=int, default=1024, help="size of the grBCM global/communication set")
-    ap.add_argument("--cpu-n", type=int, default=8192, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=8192, help="size of the small CPU-baseline sample")
     ap.add_argument("--cpu-n-written", type=int, default=4096, help="size of the as-written CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the measured full-size CPU evaluation (~80 s)")
     ap.add_argument("--no-grbcm", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline + roofline only")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, run the collectives of the `dist` object and print it; no GPU work (launch self-test)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one process per GPU; PG_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
     # single-GPU box -- RCCL refuses two ranks on one device)
     backend = os.environ.get("PG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, %d visible (PG_BENCH_BACKEND=gloo rehearses on fewer)"
+                         % (world, world, ndev))
+    dev_index = local_rank % ndev
+    if not args.rendezvous_only:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -114,15 +188,59 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"      # where collectives take their buffers
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def dist_report(nwords):
+        """Who took part: every rank reports (rank, device index); the shared-gradient all-reduce is timed alone."""
+        if world == 1:
+            return {"backend": None, "world": 1, "ranks": [0], "devices": [dev_index]}
+        me = torch.tensor([rank, dev_index], dtype=torch.int64, device=cdev)
+        got = [torch.zeros_like(me) for _ in range(world)]
+        dist.all_gather(got, me)
+        buf = torch.zeros(nwords, dtype=torch.float64, device=cdev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        sync()
+        t_ar = max_over_ranks((time.perf_counter() - t0) / 50)
+        return {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                "ranks": [int(g[0]) for g in got], "devices": [int(g[1]) for g in got],
+                "allreduce_us": 1e6 * t_ar, "allreduce_doubles": int(buf.numel()),
+                "transport": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal: ranks may share GPUs)"}
+
+    if args.rendezvous_only:
+        rep = dist_report(2 + args.d + 2)
+        if rank == 0:
+            print(json.dumps({"dist": rep}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import pygpr_amd as pg
+    from pygpr_amd import _lib
     from pygpr_amd._ops import get_ops, make_spec
 
     ops = get_ops()
     n, d, ng = args.n, args.d, args.ng
     nls = n - ng
     cov = pg.Compose([pg.Squared_exponential(), pg.White_noise()])
-    hp = np.concatenate([[1.0], np.ones(d), [0.1]])            # sigma, l_1..l_d, sigma_n
+    hp = default_hp(d)
 
     # one expert per rank, n = ng + nls points: global set (shared) + own shard
     xg, yg = synth_expert(ng, d, 99)
@@ -147,13 +265,6 @@ def main():
         val, grad = loss.loss_and_grad(hp)
     barrier()
     elapsed = time.perf_counter() - t0
-    def max_over_ranks(v):
-        if world == 1:
-            return v
-        tt = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-
     elapsed = max_over_ranks(elapsed)
     value = world * args.steps / elapsed
 
@@ -166,39 +277,65 @@ def main():
                         "Compose([Squared_exponential, White_noise]), hp sigma=1 l=1 sigma_n=0.1, jitter 1e-7; "
                         "N>1: grBCM shared-hp co-training (each rank's expert = %d global + %d own points), one "
                         "all-reduce of [1+nhp] per step" % (n, d, ng, nls),
-            "experts_per_gpu": 1, "nlml": float(val), "grad_inf": float(np.abs(grad).max()),
+            "experts_per_gpu": 1, "nlml_sum_over_ranks": float(val), "grad_inf": float(np.abs(grad).max()),
         },
+        "build": _lib.build_id(),
     }
 
+    out["dist"] = dist_report(2 + d + 2)      # [NLML, gradient (nhp = d + 2), status]
+
+    local = exp = None
     if rank == 0:
         # ---- roofline of the dominant kernel: one profiled evaluation (events around every GEMM launch)
         local = pg.MLE(model.gpl)            # rank-local evaluation: no collective inside a rank-0-only section
         local.memoize = False
-        local.loss_and_grad(hp[None, :].copy())
+        l0, g0 = local.loss_and_grad(hp[None, :].copy())
+        l0, g0 = float(l0[0]), g0[0]
         ops.profile(1)
         local.loss_and_grad(hp[None, :].copy())
         torch.cuda.synchronize()
         ops.profile(0)
         flops, ms, launches = ops.profile_read()
         achieved = flops / ms / 1e9 if ms > 0 else 0.0
+        eval_tflops = float(n) ** 3 / (elapsed / args.steps) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,   # filled from the committed PMC passes below
             "kernel": "pg_gemm_kernel<double,...> (MFMA GEMM core, all instantiations) over one evaluation",
+            "profile_mode": "single-stream: look-ahead off, every GEMM-core launch timed alone with HIP events on its launch "
+                            "stream (pg_profile); frac is the GEMM core's, frac_end_to_end the headline schedule's",
             "launches": launches, "avg_launch_ms": ms / max(launches, 1), "flops_per_launch": flops / max(launches, 1),
-            "algorithmic_flops_per_eval": float(n) ** 3, "eval_tflops": float(n) ** 3 / (elapsed / args.steps) / 1e12,
+            "algorithmic_flops_per_eval": float(n) ** 3, "eval_tflops": eval_tflops,
+            "frac_end_to_end": eval_tflops / FP64_MATRIX_PEAK_TFLOPS,
         }
         # HBM-side bytes of the GEMM-core launches: PMC counters cannot be read from inside this process; they come
         # from separate rocprofv3 --pmc passes over the same evaluation (tools/probe_eval_once.py, tools/pmc_summary.py),
-        # committed under profiles/.  Only valid for the default problem size.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_eval_traffic.json")
+        # committed under profiles/ together with the identity of the build they were taken on.  A summary taken on
+        # another build (kernel sources changed since) is not reported.
+        pmc_name = "r02_pmc_eval_traffic.json"
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if n == 16384 and os.path.exists(pmc):
             with open(pmc) as fh:
-                k = json.load(fh)["kernels"]["gemm_core"]
-            out["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = "B per launch (2 x FETCH_SIZE + WRITE_SIZE, %d launches, %.1f GB per evaluation)" % (
-                k["launches"], k["hbm_bytes"] / 1e9)
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_eval_traffic.json"
+                js = json.load(fh)
+            k = js["kernels"]["gemm_core"]
+            if js.get("build", {}).get("src_sha16") == out["build"]["src_sha16"]:
+                out["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "B per launch (2 x FETCH_SIZE + WRITE_SIZE, %d launches, %.1f GB per evaluation)" % (
+                    k["launches"], k["hbm_bytes"] / 1e9)
+                out["roofline"]["traffic_source"] = "profiles/" + pmc_name
+            else:
+                out["roofline"]["traffic_note"] = ("profiles/%s was taken on build %s, this is %s: not reported"
+                                                   % (pmc_name, js.get("build", {}).get("src_sha16"), out["build"]["src_sha16"]))
+        # ---- the published size is checked, not only printed
+        exp_nlml = EXPECTED_NLML.get((n, d, ng))
+        if exp_nlml is not None:
+            rel = abs(l0 - exp_nlml) / abs(exp_nlml)
+            out["nlml_check"] = {"nlml": l0, "expected": exp_nlml, "rel_err": rel, "rtol": NLML_RTOL,
+                                 "grad_inf": float(np.abs(g0).max())}
+            assert rel < NLML_RTOL, "NLML at the published size moved: %r" % (out["nlml_check"],)
+
+    legs = rank == 0 and world == 1 and not args.no_legs
+    if legs:
         # potrf alone and the covariance build, HIP events on torch's current stream (the library's stream)
         exp = model.gpl._device_experts()[0]
         npad = exp.n_pad
@@ -228,18 +365,39 @@ def main():
             "frac": bytes_build / t_build / 1e6 / HBM_PEAK_GBS, "ms": t_build, "algorithmic_bytes": bytes_build,
         }
         t_lower = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)
+        bytes_lower = 4.0 * n * (n + 64) + 8.0 * n * d
+        out["roofline_kernel_build"]["lower_only"] = {"ms": t_lower, "algorithmic_bytes": bytes_lower,
+                                                      "achieved": bytes_lower / t_lower / 1e6,
+                                                      "frac": bytes_lower / t_lower / 1e6 / HBM_PEAK_GBS}
 
         def fac():
             ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7)
             ops.potrf(a, invd, info)
 
-        t_potrf = timed(fac, 3) - t_lower
-        out["cholesky"] = {"ms": t_potrf, "tflops": n ** 3 / 3.0 / t_potrf / 1e9,
-                           "frac_of_fp64_matrix_peak": n ** 3 / 3.0 / t_potrf / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
+        def chol_leg(nn):
+            t = timed(fac, 3) - t_lower * (nn / float(n)) ** 2
+            return {"n": nn, "ms": t, "tflops": nn ** 3 / 3.0 / t / 1e9,
+                    "frac_of_fp64_matrix_peak": nn ** 3 / 3.0 / t / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
+
+        out["cholesky"] = chol_leg(n)
         del a, invd
         # BASELINE config 2: single GP, N=8192 D=8 fp64 -- kernel build + Cholesky + alpha (fit), then mean + diag variance
         # at 8192 test points (predict; includes L^-1 on the first call)
         x2, y2 = synth_expert(8192, d, 4242)
+        if n == 16384:      # the Cholesky alone at config 2's size
+            x2d = torch.from_numpy(x2).cuda()
+            a = ops.empty(8192, 8192)
+            invd = ops.potrf_workspace(8192, torch.float64)
+
+            def fac2():
+                ops.kernel_build(spec, hpd, x2d, None, a, lower_only=True, jitter=1e-7)
+                ops.potrf(a, invd, info)
+
+            t2l = timed(lambda: ops.kernel_build(spec, hpd, x2d, None, a, lower_only=True, jitter=1e-7), 3)
+            t2 = timed(fac2, 5) - t2l
+            out["cholesky_n8192"] = {"n": 8192, "ms": t2, "tflops": 8192 ** 3 / 3.0 / t2 / 1e9,
+                                     "frac_of_fp64_matrix_peak": 8192 ** 3 / 3.0 / t2 / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
+            del a, invd, x2d
         gp2 = pg.Exact_GP(torch.from_numpy(x2), torch.from_numpy(y2), cov, eager_inverse=True)   # variances follow
         gp2.set_params(torch.from_numpy(hp))
         xs2 = torch.from_numpy(np.random.default_rng(4321).random((8192, d))).cuda()
@@ -258,14 +416,15 @@ def main():
                                            "follow); predict = K* build + mean + diag variance"}
         del gp2
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, d, min(args.cpu_n, n))
+            e0 = model.gpl._x[0].numpy(), model.gpl._y[0].numpy()
+            out["cpu_baseline"] = cpu_baseline(e0[0], e0[1], hp, min(args.cpu_n, n), l0, g0, not args.no_cpu_full)
             out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
             out["cpu_baseline_as_written"] = cpu_baseline_as_written(n, d, min(args.cpu_n_written, n))
 
     # ---- secondary metric: grBCM committee prediction throughput (BASELINE config 4)
-    if not args.no_grbcm:
-        del model, loss
-        torch.cuda.empty_cache()
+    del model, loss, local, exp
+    torch.cuda.empty_cache()
+    if not args.no_grbcm and not args.no_legs:
         nc, nls4, ng4, d4, m4, mb = 8, 8192, 1024, 16, 65536, 8192
         xg4, yg4 = synth_expert(ng4, d4, 7)
         sh = [synth_expert(nls4, d4, 100 + c) for c in range(nc)]
@@ -289,6 +448,41 @@ def main():
                       "diag variance; experts sharded over %d rank(s); one [3,m] all-reduce per batch" % (ng4, nls4, d4, m4, mb, world),
             "mean_abs": float(mu.abs().mean()), "var_mean": float(var.mean()),
         }
+        del g4, xs
+
+    # ---- BASELINE config 5: grBCM, 8 experts x (1024 + 32768) points, Matern-5/2, fp32, shared-hp co-training objective
+    # sum_c NLML_c and its gradient (GRBCM_MLE): 1 warm-up + 3 evaluations.  At N = 1 the 8 experts run one after another
+    # on the one GPU (with one expert per GPU each rank does 1/8 of this plus one [1 + nhp] all-reduce).
+    if legs:
+        torch.cuda.empty_cache()
+        nc5, nls5, ng5, d5 = 8, 32768, 1024, 16
+        rng = np.random.default_rng(1234)
+        f5 = lambda x: np.sin(-x.sum(-1)) + 0.1 * rng.standard_normal(x.shape[:-1])   # noqa: E731
+        xl5 = rng.random((nc5, nls5, d5)); yl5 = f5(xl5)
+        xg5 = rng.random((ng5, d5)); yg5 = f5(xg5)
+        t32 = lambda a: torch.from_numpy(a).to(torch.float32)   # noqa: E731
+        cov5 = pg.Compose([pg.Matern52(), pg.White_noise()])
+        m5 = pg.GRBCM(t32(xl5), t32(yl5), t32(xg5), t32(yg5), cov5)
+        obj5 = pg.GRBCM_MLE(m5)
+        obj5.memoize = False
+        hp5 = np.concatenate([[1.0], 0.5 * np.ones(d5), [0.1]])
+        obj5.loss_and_grad(hp5.copy())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3):
+            l5, g5 = obj5.loss_and_grad(hp5 * (1.0 + 1e-3 * (i + 1)))
+        torch.cuda.synchronize()
+        t5 = (time.perf_counter() - t0) / 3
+        n5 = ng5 + nls5
+        flop5 = nc5 * float(n5) ** 3
+        out["cfg5_cotrain"] = {
+            "config": "grBCM co-training objective, %d experts x (%d global + %d own) = %d points each, D=%d, Matern-5/2 + noise, "
+                      "fp32, shared hp; 1 warm-up + 3 evaluations of sum_c NLML_c and its gradient on ONE GPU" % (nc5, ng5, nls5, n5, d5),
+            "dtype": "f32", "ms_per_eval": 1e3 * t5, "ms_per_expert": 1e3 * t5 / nc5, "evals_per_s": 1.0 / t5,
+            "tflops": flop5 / t5 / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "frac_of_fp32_matrix_peak": flop5 / t5 / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "algorithmic_flops_per_eval": flop5, "loss": float(l5), "grad_inf": float(np.abs(g5).max()),
+        }
+        del m5, obj5
 
     if rank == 0:
         print(json.dumps(out), flush=True)

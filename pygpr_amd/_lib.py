@@ -106,3 +106,19 @@ def last_error():
 def check(rc, what=""):
     if rc != 0:
         raise RuntimeError("libpygpr_hip %s failed (rc=%d): %s" % (what, rc, last_error()))
+
+
+def build_id():
+    """Identity of the running build: hash of the kernel sources + C header (what a profile must match to describe
+    this build) and of the shared object itself."""
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)) + [HEADER]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if path.endswith((".hip", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    lib = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16] if os.path.exists(LIB_PATH) else None
+    return {"src_sha16": h.hexdigest()[:16], "lib_sha16": lib}

@@ -24,10 +24,12 @@ from .covar import Covar, layout, spec_of
 _CHUNK = 8192  # test points per device batch
 
 
-def _lin_alg_error(info: int):
-    return torch.linalg.LinAlgError(
+def _lin_alg_error(info: int, note: str = ""):
+    err = torch.linalg.LinAlgError(
         "cholesky: The factorization could not be completed because the input is not positive-definite "
-        "(the leading minor of order %d is not positive-definite)." % info)
+        "(the leading minor of order %d is not positive-definite)%s." % (info, note))
+    err.pg_info = int(info)
+    return err
 
 
 class GPR:

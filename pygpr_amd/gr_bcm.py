@@ -36,15 +36,23 @@ def expert_block(nc, rank, world):
     return lo, min(lo + per, nc)
 
 
-def _all_reduce_sum(t, group=None):
-    """Sum a small tensor over ranks; NCCL/RCCL needs device memory, gloo takes host memory."""
+def _all_reduce(t, op, group=None):
+    """Reduce a small tensor over ranks; NCCL/RCCL needs device memory, gloo takes host memory."""
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(h, op=op, group=group)
         t.copy_(h)
     else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t, op=op, group=group)
     return t
+
+
+def _all_reduce_sum(t, group=None):
+    return _all_reduce(t, dist.ReduceOp.SUM, group)
+
+
+def _all_reduce_max(t, group=None):
+    return _all_reduce(t, dist.ReduceOp.MAX, group)
 
 
 class GRBCM(GPR):
@@ -101,19 +109,32 @@ class GRBCM(GPR):
             self.gpl.set_params(params_all[self.lo: self.hi])
 
     # ---- aggregation ------------------------------------------------------------------------
+    def _reduce_terms(self, flat, m, status=0):
+        """The ONE all-reduce of a test batch: [3, m] aggregation terms + one status word, so that a factorisation
+        that failed on one rank (LinAlgError before it could join the collective) fails on every rank instead of
+        leaving the others blocked in the all-reduce."""
+        if status:
+            flat[3 * m:] = float(status)
+        _all_reduce_sum(flat, self.group)
+        st = int(round(float(flat[3 * m].item())))
+        if st:
+            raise _lin_alg_error(status if status else st,
+                                 "" if status else " (reported by another rank of the committee)")
+
     def _aggregate_device(self, mean_g, var_g, means_l, vars_l):
         """Device tensors in, device tensors out.  beta/prec rows: [global, owned local experts...]."""
         ops = get_ops()
         m = mean_g.numel()
         nloc = len(means_l)
-        sums = ops.zeros(3, m, dtype=torch.float64)
+        flat = ops.zeros(3 * m + 1, dtype=torch.float64)
+        sums = flat[: 3 * m].view(3, m)
         beta = ops.empty(nloc + 1, m, dtype=torch.float64)
         prec = ops.empty(nloc + 1, m, dtype=torch.float64)
         for c in range(nloc):
             ops.grbcm_local_terms(means_l[c], vars_l[c], var_g, (self.lo + c) == 0, True, sums,
                                   beta[c + 1], prec[c + 1])
         if self.distributed:
-            _all_reduce_sum(sums, self.group)
+            self._reduce_terms(flat, m)
         mean, var = ops.empty(m, dtype=mean_g.dtype), ops.empty(m, dtype=mean_g.dtype)
         ops.grbcm_finish(sums, mean_g, var_g, mean, var, beta[0], prec[0])
         self.beta, self.prec, self._sums = beta, prec, sums
@@ -161,10 +182,12 @@ class GRBCM(GPR):
         ops.grbcm_weighted_prec(p0, self.beta[0].contiguous(), acc, m, True)
         cov, info = ops.spd_inverse_lower(acc)
         infos.append(info)
-        for i in infos:
-            k = int(i.item())
-            if k:
-                raise _lin_alg_error(k)
+        bad = max(int(i.item()) for i in infos)
+        if self.distributed:            # every rank raises together (the m x m inverses above are rank-local)
+            t = torch.tensor([float(bad)], dtype=torch.float64, device=acc.device)
+            bad = int(round(float(_all_reduce_max(t, self.group).item())))
+        if bad:
+            raise _lin_alg_error(bad)
         ops.symmetrize(cov, cov.shape[0])
         mean = ops.empty(m, dtype=mean_g.dtype)
         ops.grbcm_finish_full(self._sums, mean_g, var_g, cov, mean)
@@ -193,11 +216,18 @@ class GRBCM(GPR):
         ops = get_ops()
         want = "diag" if var == "diag" else "full"
         xsd = ops.to_device(xs.reshape(-1, xs.shape[-1]), self.gpg.dtype)
-        mg, vg = self.gpg._predict_device(xsd, want)
-        if self.gpl is not None:
-            ml, vl = self.gpl._predict_device(xsd, want)
-        else:
-            ml, vl = [], []
+        try:
+            mg, vg = self.gpg._predict_device(xsd, want)
+            if self.gpl is not None:
+                ml, vl = self.gpl._predict_device(xsd, want)
+            else:
+                ml, vl = [], []
+        except torch.linalg.LinAlgError as err:
+            if not self.distributed:
+                raise
+            m = xsd.shape[0]                # join the batch's all-reduce with the status word set, then raise
+            self._reduce_terms(ops.zeros(3 * m + 1, dtype=torch.float64), m, getattr(err, "pg_info", 1) or 1)
+            raise
         if want == "diag":
             mean, out = self._aggregate_device(mg[0], vg[0], ml, vl)
         else:
@@ -238,16 +268,31 @@ class GRBCM_MLE(Loss):
         return vec
 
     def _local(self, params, want_grad):
+        """[sum_c NLML_c, gradient, status]: the status word rides in the same all-reduce, so that a non-PD expert on
+        one rank raises LinAlgError on every rank instead of leaving the others blocked in the collective."""
         nhp = np.asarray(params).shape[-1]
-        vec = np.zeros(1 + nhp)
+        vec = np.zeros(2 + nhp)
+        failed = None
         if self._mle is not None:
             nloc = self.model.hi - self.model.lo
             rows = np.broadcast_to(np.asarray(params, dtype=np.float64), (nloc, nhp))
-            loss, grad = self._mle._evaluate(rows, want_grad)
-            vec[0] = np.sum(loss)
-            if want_grad:
-                vec[1:] = np.sum(grad, axis=0)
-        return self._reduce(vec)
+            try:
+                loss, grad = self._mle._evaluate(rows, want_grad)
+                vec[0] = np.sum(loss)
+                if want_grad:
+                    vec[1: 1 + nhp] = np.sum(grad, axis=0)
+            except torch.linalg.LinAlgError as err:
+                if not self.model.distributed:
+                    raise
+                failed = err
+                vec[:] = 0.0
+                vec[1 + nhp] = float(getattr(err, "pg_info", 1) or 1)
+        vec = self._reduce(vec)
+        if failed is not None:
+            raise failed
+        if vec[1 + nhp] != 0.0:
+            raise _lin_alg_error(int(round(vec[1 + nhp])), " (reported by another rank of the committee)")
+        return vec[: 1 + nhp]
 
     def loss(self, params):
         vec = self._local(params, False)

@@ -38,6 +38,27 @@ def _worker(rank, world, port, out_dir):
         loss, grad = pg.GRBCM_MLE(m).loss_and_grad(g[p + "hpg"].copy())
         res["mu%d" % case], res["var%d" % case] = mu.numpy(), var.numpy()
         res["loss%d" % case], res["grad%d" % case] = np.array(loss), grad
+        # full-covariance committee over the ranks (shared hp as in the fixture): the [3, m] all-reduce, then the
+        # [m_pad, m_pad] weighted-precision all-reduce with the 1/world padding diagonal
+        m.set_params(T(g[p + "hpg"]))
+        mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
+        res["muf%d" % case], res["covf%d" % case] = mu_f.numpy(), cov_f.numpy()
+    # a non-positive-definite expert on the LAST rank only: every rank must raise, none may hang in the collective
+    p = "g1_"
+    xl = g[p + "xl"].copy()
+    xl[-1, 3, 0] = np.nan
+    bad = pg.GRBCM(T(xl), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), pg.Compose([pg.Squared_exponential(), pg.White_noise()]),
+                   distributed=True)
+    bad.set_params(T(g[p + "hpg"]))
+    raised = []
+    for call in (lambda: bad.predict(T(g[p + "xs"]), var="diag"), lambda: pg.GRBCM_MLE(bad).loss_and_grad(g[p + "hpg"].copy()),
+                 lambda: bad.predict(T(g[p + "xs"]), var="full")):
+        try:
+            call()
+            raised.append(0)
+        except torch.linalg.LinAlgError as err:
+            raised.append(2 if "another rank" in str(err) else 1)
+    res["raised"] = np.array(raised)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -60,3 +81,24 @@ def test_grbcm_two_ranks_gloo(tmp_path, golden):
         for o in outs:
             np.testing.assert_allclose(o["loss%d" % case], sum(r[0] for r in ref), rtol=1e-10)
             np.testing.assert_allclose(o["grad%d" % case], sum(r[1] for r in ref), rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(o["covf%d" % case], g[p + "cov_full"], rtol=1e-6, atol=1e-10)
+            np.testing.assert_allclose(o["muf%d" % case], g[p + "mu_full"], rtol=1e-6, atol=1e-9)
+    # failure on the last rank: it raises its own error (1), the other rank the relayed one (2) -- in all three calls
+    assert outs[world - 1]["raised"].tolist() == [1, 1, 1]
+    assert outs[0]["raised"].tolist() == [2, 2, 2]
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): bench.py spawns the ranks itself, they rendezvous,
+    all-gather their rank numbers and time the [1 + nhp + 1] all-reduce; rank 0's JSON line is relayed."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PG_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)["dist"]
+    assert rep["world"] == 2 and rep["ranks"] == [0, 1] and rep["backend"] == "gloo" and rep["allreduce_us"] > 0
