@@ -290,7 +290,7 @@ def main():
         local = pg.MLE(model.gpl)            # rank-local evaluation: no collective inside a rank-0-only section
         local.memoize = False
         l0, g0 = local.loss_and_grad(hp[None, :].copy())
-        l0, g0 = float(l0[0]), g0[0]
+        l0, g0 = float(np.atleast_1d(l0)[0]), np.atleast_2d(g0)[0]
         ops.profile(1)
         local.loss_and_grad(hp[None, :].copy())
         torch.cuda.synchronize()
@@ -337,7 +337,7 @@ def main():
     legs = rank == 0 and world == 1 and not args.no_legs
     if legs:
         # potrf alone and the covariance build, HIP events on torch's current stream (the library's stream)
-        exp = model.gpl._device_experts()[0]
+        exp = model.gpl._device_data()[0]
         npad = exp.n_pad
         spec = make_spec([0], [0], [d + 1])
         hpd = torch.from_numpy(hp).cuda()

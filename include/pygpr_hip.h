@@ -31,12 +31,16 @@ extern "C" {
 #define PG_F32 1
 #define PG_KIND_RBF 0      /* Squared_exponential, covar.py:84-206 */
 #define PG_KIND_MATERN52 1 /* new (not in the reference), same hp layout */
+#define PG_KIND_SQDIST 2   /* pg_kernel_build only: the scaled squared distance itself, sum_k l_k^2 (x_k - x'_k)^2 --
+                              Squared_exponential.distance (covar.py:102-127) when l = 1 */
 #define PG_MAX_COMP 4
 #define PG_MAX_DIM 64
 
 typedef struct pg_ctx* pg_handle;
 
-/* A Compose([...]) of up to PG_MAX_COMP stationary kernels plus white-noise terms (covar.py:28-81). */
+/* A Compose([...]) of up to PG_MAX_COMP stationary kernels plus white-noise terms (covar.py:28-81).  A longer Compose is
+ * evaluated in passes of PG_MAX_COMP children (pg_kernel_build's `accumulate`; the gradient entries of different
+ * children are disjoint, so pg_nlml_grad / pg_kernel_grad_build passes simply write different entries). */
 typedef struct pg_covspec {
     int ncomp;                  /* stationary components                                     */
     int kind[PG_MAX_COMP];      /* PG_KIND_*                                                 */
@@ -47,16 +51,21 @@ typedef struct pg_covspec {
 
 int pg_version(void);
 const char* pg_last_error(void);
+/* A handle owns three HIP streams (panel / update / background) and a pool of events.  Release it with pg_destroy when
+ * done; handles still alive at process exit are destroyed by the library itself (a C atexit handler registered by the
+ * first pg_create, so it runs before the HIP runtime's own teardown).  pg_destroy on an already released handle is a no-op. */
 int pg_create(pg_handle* h);
 int pg_destroy(pg_handle h);
 
 /* Covariance assembly.  Replaces Compose/Squared_exponential/White_noise.kernel (covar.py:50-62,
  * 129-167, 227-245).  Xc == NULL: symmetric build on Xr (K[i][j], i,j < nr; diagonal gets
  * sum(sigma_n^2) + jitter as in gpr.py:68 / loss.py:38); lower_only skips tiles above the diagonal.
- * Otherwise a cross build K[i][j] = k(Xr_i, Xc_j) (covar.py:152-161; no noise term, covar.py:243). */
+ * Otherwise a cross build K[i][j] = k(Xr_i, Xc_j) (covar.py:152-161; no noise term, covar.py:243).
+ * accumulate != 0: K += (the sum over children of Compose.kernel, covar.py:57-60, continued in a further pass;
+ * the padding is then left alone).  d <= PG_MAX_DIM. */
 int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* Xr, long ldr,
-                    int nr, const void* Xc, long ldc, int nc, int d, int lower_only, double jitter, void* K,
-                    long ldk, int rows_pad, int cols_pad, void* stream);
+                    int nr, const void* Xc, long ldc, int nc, int d, int lower_only, int accumulate, double jitter,
+                    void* K, long ldk, int rows_pad, int cols_pad, void* stream);
 
 /* dK[nhp][n][n] (contiguous, unpadded): the stack Covar.kernel_and_grad returns (covar.py:64-81,
  * 169-206, 247-269).  Drop-in surface only -- the NLML path never materialises it. */

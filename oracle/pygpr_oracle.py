@@ -444,3 +444,9 @@ def synth(n, d, seed=1234, noise=0.1):
     x = rng.random((n, d))
     y = np.sin(-x.sum(1)) + noise * rng.standard_normal(n)
     return x, y
+
+
+def se_distance(x, xp=None, form="gemm"):
+    """Squared_exponential.distance, PyGPR/covar.py:102-127: squared Euclidean distances of the inputs as given
+    ([n,n], or [m,n] with rows = xp)."""
+    return _sqdist(x, xp, form)

@@ -4,13 +4,13 @@ from .gpr import GPR, Exact_GP
 from .covar import Squared_exponential, Matern52, Covar, Compose, White_noise
 from .loss import Loss, MLE
 from .opt import Opt, CG, Nelder_Mead, BFGS_Quad, CG_Quad, hessian
-from .gr_bcm import GRBCM, GRBCM_MLE
+from .gr_bcm import GRBCM, GRBCM_MLE, log_likelihood_batched
 from .hp_update import get_learn_rate
 from .scikit_model import SK_WRAP
-from .sampler import UNIFORM, MATERN1, cluster_samples, euclidean_dist
+from .sampler import UNIFORM, MATERN1, sample_gp, cluster_samples, euclidean_dist
 
 __all__ = [
     "GPR", "Exact_GP", "Squared_exponential", "Matern52", "Covar", "Compose", "White_noise", "Loss", "MLE", "Opt",
     "CG", "Nelder_Mead", "BFGS_Quad", "CG_Quad", "hessian", "GRBCM", "GRBCM_MLE", "get_learn_rate", "SK_WRAP",
-    "UNIFORM", "MATERN1", "cluster_samples", "euclidean_dist",
+    "UNIFORM", "MATERN1", "cluster_samples", "euclidean_dist", "sample_gp", "log_likelihood_batched",
 ]

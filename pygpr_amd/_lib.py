@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpygpr_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pygpr_hip.h")
 
 PG_F64, PG_F32 = 0, 1
-PG_KIND_RBF, PG_KIND_MATERN52 = 0, 1
+PG_KIND_RBF, PG_KIND_MATERN52, PG_KIND_SQDIST = 0, 1, 2
 PG_MAX_COMP, PG_MAX_DIM = 4, 64
 PAD = 256  # every dimension given to the O(n^3) entry points is a multiple of this
 
@@ -35,7 +35,7 @@ _SIGS = {
     "pg_last_error": (C.c_char_p, []),
     "pg_create": (_i, [C.POINTER(_vp)]),
     "pg_destroy": (_i, [_vp]),
-    "pg_kernel_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _vp, _l, _i, _i, _i, _d, _vp, _l, _i, _i, _vp]),
+    "pg_kernel_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _d, _vp, _l, _i, _i, _vp]),
     "pg_kernel_grad_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _vp]),
     "pg_potrf_worksize": (_l, [_i, _i]),
     "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),

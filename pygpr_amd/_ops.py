@@ -3,6 +3,7 @@ produced by libpygpr_hip through the C ABI (include/pygpr_hip.h).  No CPU path e
 `get_ops()` raises when the library or a GPU is missing."""
 import atexit
 import ctypes as C
+import os
 
 import torch
 
@@ -39,7 +40,11 @@ class HipOps:
         _lib.check(self.lib.pg_create(C.byref(h)), "pg_create")
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
-        atexit.register(self.close)   # destroy the handle's streams/events before the HIP runtime is torn down
+        # the library destroys live handles itself at process exit (capi.hip: C atexit registered by pg_create); closing
+        # here as well releases the streams while torch's allocator is still up.  PG_NO_PY_ATEXIT=1 leaves it to the library
+        # (used once to verify the library-side teardown under rocprofv3).
+        if not os.environ.get("PG_NO_PY_ATEXIT"):
+            atexit.register(self.close)
 
     def close(self):
         if getattr(self, "h", None) is not None:
@@ -72,24 +77,38 @@ class HipOps:
 
     # -- covariance assembly ------------------------------------------------------------------
     def kernel_build(self, spec, hp, xr, xc, out, lower_only=False, jitter=0.0):
-        """out[rows_pad, cols_pad] <- k(xr, xc) (xc None: symmetric + noise/jitter diagonal)."""
+        """out[rows_pad, cols_pad] <- k(xr, xc) (xc None: symmetric + noise/jitter diagonal).  `spec` is one pg_covspec
+        or the list of passes of a long Compose (make_specs): later passes accumulate."""
         self._chk(hp, xr, xc, out)
         assert hp.dtype == torch.float64
         nr, d = xr.shape
         nc = xc.shape[0] if xc is not None else nr
-        _lib.check(self.lib.pg_kernel_build(
-            self.h, _code(out.dtype), C.byref(spec), _p(hp), _p(xr), xr.stride(0), nr,
-            _p(xc), xc.stride(0) if xc is not None else 0, nc, d, int(lower_only), float(jitter),
-            _p(out), out.stride(0), out.shape[0], out.shape[1], self._st()), "pg_kernel_build")
+        for i, sp in enumerate(_passes(spec)):
+            if i > 0 and xc is not None and sp.ncomp == 0:
+                continue                      # a noise-only pass adds nothing to a cross build (covar.py:243)
+            _lib.check(self.lib.pg_kernel_build(
+                self.h, _code(out.dtype), C.byref(sp), _p(hp), _p(xr), xr.stride(0), nr,
+                _p(xc), xc.stride(0) if xc is not None else 0, nc, d, int(lower_only), int(i > 0),
+                float(jitter) if i == 0 else 0.0, _p(out), out.stride(0), out.shape[0], out.shape[1], self._st()),
+                "pg_kernel_build")
         return out
 
     def kernel_grad_build(self, spec, hp, x, out):
         """out[nhp, n, n] <- dK/dtheta stack (public Covar.kernel_and_grad only)."""
         self._chk(hp, x, out)
         n, d = x.shape
-        _lib.check(self.lib.pg_kernel_grad_build(self.h, _code(out.dtype), C.byref(spec), _p(hp), _p(x), x.stride(0),
-                                                 n, d, _p(out), self._st()), "pg_kernel_grad_build")
+        for sp in _passes(spec):              # passes write the slabs of different children
+            _lib.check(self.lib.pg_kernel_grad_build(self.h, _code(out.dtype), C.byref(sp), _p(hp), _p(x), x.stride(0),
+                                                     n, d, _p(out), self._st()), "pg_kernel_grad_build")
         return out
+
+    def sqdist(self, xr, xc, out):
+        """out[rows_pad, cols_pad] <- |xr_i - xc_j|^2 (xc None: xr against itself), direct differences:
+        Squared_exponential.distance (covar.py:102-127) through the covariance tile kernel."""
+        d = xr.shape[1]
+        spec = make_spec([_lib.PG_KIND_SQDIST], [0], [])
+        ones = torch.ones(d + 1, dtype=torch.float64, device=self.device)
+        return self.kernel_build(spec, ones, xr, xc, out)
 
     # -- factorisation and solves -------------------------------------------------------------
     def potrf_workspace(self, n_pad, dtype):
@@ -156,9 +175,10 @@ class HipOps:
 
     def nlml_grad(self, spec, hp, x, n, kinv, alpha, grad, work):
         self._chk(hp, x, kinv, alpha, grad, work)
-        _lib.check(self.lib.pg_nlml_grad(self.h, _code(kinv.dtype), C.byref(spec), _p(hp), _p(x), x.stride(0), n,
-                                         x.shape[1], _p(kinv), kinv.stride(0), _p(alpha), _p(grad), grad.numel(),
-                                         _p(work), work.numel(), self._st()), "pg_nlml_grad")
+        for sp in _passes(spec):              # each pass fills the gradient entries of its own children
+            _lib.check(self.lib.pg_nlml_grad(self.h, _code(kinv.dtype), C.byref(sp), _p(hp), _p(x), x.stride(0), n,
+                                             x.shape[1], _p(kinv), kinv.stride(0), _p(alpha), _p(grad), grad.numel(),
+                                             _p(work), work.numel(), self._st()), "pg_nlml_grad")
 
     # -- prediction ---------------------------------------------------------------------------
     def predict_mean_q(self, ks, minv, alpha, mean, var, kss, work):
@@ -265,10 +285,23 @@ def get_ops():
     return _OPS
 
 
+def _passes(spec):
+    return spec if isinstance(spec, (list, tuple)) else [spec]
+
+
+def make_specs(kinds, offs, noise_offs):
+    """The passes of a Compose of any length: pg_covspec holds PG_MAX_COMP stationary and PG_MAX_COMP noise children, a
+    longer sum (the reference's Compose is unlimited, covar.py:28-81) is evaluated PG_MAX_COMP children at a time."""
+    q = _lib.PG_MAX_COMP
+    npass = max(1, -(-len(kinds) // q), -(-len(noise_offs) // q))
+    return [make_spec(kinds[i * q: (i + 1) * q], offs[i * q: (i + 1) * q], noise_offs[i * q: (i + 1) * q]) for i in range(npass)]
+
+
 def make_spec(kinds, offs, noise_offs):
     s = CovSpec()
     if len(kinds) > _lib.PG_MAX_COMP or len(noise_offs) > _lib.PG_MAX_COMP:
-        raise ValueError("a Compose may hold at most %d stationary and %d noise kernels" % (_lib.PG_MAX_COMP, _lib.PG_MAX_COMP))
+        raise ValueError("one pg_covspec holds at most %d stationary and %d noise kernels (make_specs splits a longer Compose)"
+                         % (_lib.PG_MAX_COMP, _lib.PG_MAX_COMP))
     s.ncomp = len(kinds)
     for i, (k, o) in enumerate(zip(kinds, offs)):
         s.kind[i], s.off[i] = k, o

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._ops import get_ops, make_spec, pad_to
+from ._ops import get_ops, make_specs, pad_to
 
 
 class Covar(Protocol):
@@ -54,8 +54,10 @@ def layout(cov, d):
 
 
 def spec_of(cov, d):
+    """(passes, nhp): the pg_covspec list the device ops take (one entry unless the Compose has more than
+    PG_MAX_COMP stationary or noise children)."""
     kinds, offs, noise, nhp = layout(cov, d)
-    return make_spec(kinds, offs, noise), nhp
+    return make_specs(kinds, offs, noise), nhp
 
 
 class _DeviceKernel:
@@ -141,6 +143,38 @@ class Squared_exponential(_DeviceKernel):
 
     def init_params(self, x: Tensor) -> Tensor:  # covar.py:96-100
         return torch.ones(self.get_params_shape(x), dtype=torch.float64)
+
+    def distance(self, x: Tensor, xp: Tensor = None) -> Tensor:
+        """Squared Euclidean distances (covar.py:102-127): x [(b), n, d] -> [(b), n, n]; with xp [(b), m, d] the rows
+        are the test points, [(b), m, n]; a batch of one is squeezed away like the reference does.  Evaluated on the
+        device by the covariance tile kernel as direct sums of squared differences (the reference expands
+        -2 x x'^T + |x|^2 + |x'|^2: same value to rounding, but this one is exactly symmetric with a zero diagonal)."""
+        ops = get_ops()
+        xb = x.reshape(-1, x.shape[-2], x.shape[-1])
+        xpb = None if xp is None else xp.reshape(-1, xp.shape[-2], xp.shape[-1])
+        nb = max(xb.shape[0], 1 if xpb is None else xpb.shape[0])
+        for t in (xb, xpb):
+            if t is not None and t.shape[0] not in (1, nb):
+                raise RuntimeError("batch dimensions of x / xp do not broadcast")
+        dt = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float64
+        xd = ops.to_device(xb, dt)
+        xpd = None if xpb is None else ops.to_device(xpb, dt)
+        n = xb.shape[1]
+        outs = []
+        for b in range(nb):
+            xr = xd[b % xd.shape[0]]
+            if xpd is None:
+                buf = ops.empty(pad_to(n, 64), pad_to(n, 64), dtype=dt)
+                ops.sqdist(xr, None, buf)
+                outs.append(buf[:n, :n])
+            else:
+                xq = xpd[b % xpd.shape[0]]
+                m = xq.shape[0]
+                buf = ops.empty(pad_to(m, 64), pad_to(n, 64), dtype=dt)
+                ops.sqdist(xq, xr, buf)
+                outs.append(buf[:m, :n])
+        res = torch.stack(outs) if nb > 1 else outs[0].contiguous()
+        return res.to(x.device)
 
 
 class Matern52(Squared_exponential):

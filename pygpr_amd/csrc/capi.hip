@@ -7,8 +7,40 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
+
+// Live handles.  A handle owns priority / CU-masked streams and events; if they are still alive when the HIP runtime
+// tears itself down at process exit, the runtime's finalisers touch freed queue state (round 1: SIGSEGV in
+// __cxa_finalize under rocprofv3, after the profiler had written its output).  pg_create therefore registers a C atexit
+// handler the first time it runs -- i.e. after the HIP runtime registered its own, so it runs BEFORE the runtime's --
+// that destroys whatever the caller did not pg_destroy.
+static std::mutex g_live_mu;
+static std::vector<pg_ctx*> g_live;
+static bool g_atexit_registered = false;
+
+static void release_ctx(pg_ctx* h) {
+    (void)hipStreamDestroy(h->aux);
+    if (h->upd) (void)hipStreamDestroy(h->upd);
+    if (h->bg) (void)hipStreamDestroy(h->bg);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
+    free(h->pool);
+    delete h;
+}
+
+static void destroy_live_handles() {
+    std::vector<pg_ctx*> left;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        left.swap(g_live);
+    }
+    if (left.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (pg_ctx* h : left) release_ctx(h);
+}
 
 void pg_set_error(const char* fmt, ...) {
     va_list ap;
@@ -98,29 +130,37 @@ int pg_create(pg_handle* h) {
         }
     }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(c);
+        if (!g_atexit_registered) {
+            atexit(destroy_live_handles);
+            g_atexit_registered = true;
+        }
+    }
     *h = c;
     return 0;
 }
 
 int pg_destroy(pg_handle h) {
     if (!h) return 0;
-    (void)hipStreamDestroy(h->aux);
-    if (h->upd) (void)hipStreamDestroy(h->upd);
-    if (h->bg) (void)hipStreamDestroy(h->bg);
-    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
-    free(h->pool);
-    delete h;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        auto it = std::find(g_live.begin(), g_live.end(), h);
+        if (it == g_live.end()) return 0;      // already released (second pg_destroy, or after the exit handler ran)
+        g_live.erase(it);
+    }
+    release_ctx(h);
     return 0;
 }
 
-static int check_spec(const pg_covspec* s, const char* fn) {
+static int check_spec(const pg_covspec* s, const char* fn, bool allow_sqdist = false) {
     if (!s || s->ncomp < 0 || s->ncomp > PG_MAX_COMP || s->nnoise < 0 || s->nnoise > PG_MAX_COMP) {
         pg_set_error("%s: bad covariance spec", fn);
         return -1;
     }
     for (int c = 0; c < s->ncomp; ++c)
-        if (s->kind[c] != PG_KIND_RBF && s->kind[c] != PG_KIND_MATERN52) {
+        if (s->kind[c] != PG_KIND_RBF && s->kind[c] != PG_KIND_MATERN52 && !(allow_sqdist && s->kind[c] == PG_KIND_SQDIST)) {
             pg_set_error("%s: unknown kernel kind %d", fn, s->kind[c]);
             return -1;
         }
@@ -128,10 +168,10 @@ static int check_spec(const pg_covspec* s, const char* fn) {
 }
 
 int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* Xr, long ldr, int nr,
-                    const void* Xc, long ldc, int nc, int d, int lower_only, double jitter, void* K, long ldk,
-                    int rows_pad, int cols_pad, void* stream) {
+                    const void* Xc, long ldc, int nc, int d, int lower_only, int accumulate, double jitter, void* K,
+                    long ldk, int rows_pad, int cols_pad, void* stream) {
     NEED(h && hp && Xr && K, "null pointer");
-    if (check_spec(spec, __func__)) return -1;
+    if (check_spec(spec, __func__, true)) return -1;
     const int sym = (Xc == nullptr);
     if (sym) { Xc = Xr; ldc = ldr; nc = nr; }
     NEED(nr >= 0 && nc >= 0 && rows_pad >= nr && cols_pad >= nc && ldk >= cols_pad, "inconsistent sizes");
@@ -139,9 +179,9 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
     NEED(ldk % (dtype == PG_F64 ? 2 : 4) == 0, "ldk must keep rows 16-byte aligned");
     DISPATCH(dtype,
              pg_kbuild<double>(ST(stream), *spec, hp, (const double*)Xr, ldr, nr, (const double*)Xc, ldc, nc, d, sym,
-                               lower_only, jitter, (double*)K, ldk, rows_pad, cols_pad),
+                               lower_only, accumulate, jitter, (double*)K, ldk, rows_pad, cols_pad),
              pg_kbuild<float>(ST(stream), *spec, hp, (const float*)Xr, ldr, nr, (const float*)Xc, ldc, nc, d, sym,
-                              lower_only, jitter, (float*)K, ldk, rows_pad, cols_pad));
+                              lower_only, accumulate, jitter, (float*)K, ldk, rows_pad, cols_pad));
 }
 
 int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,

@@ -4,7 +4,7 @@
 
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
-              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, double jitter, T* K,
+              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,
               long ldk, int rows_pad, int cols_pad);
 template <typename T>
 int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,

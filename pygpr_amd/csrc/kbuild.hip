@@ -51,6 +51,7 @@ __device__ __forceinline__ float pg_exp(float x) { return expf(x); }
 
 template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, T sqd) {
     if (kind == PG_KIND_RBF) return sig2 * pg_exp(-sqd);
+    if (kind == PG_KIND_SQDIST) return sqd;    // Squared_exponential.distance (covar.py:102-127): the scaled squared distance itself
     const T s5 = (T)2.23606797749978969641;
     const T r = sqrt(sqd);
     return sig2 * ((T)1 + s5 * r + (T)(5.0 / 3.0) * sqd) * pg_exp(-s5 * r);
@@ -70,7 +71,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                         const T* __restrict__ Xr, long ldr, int nr,
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
-                                                        int symmetric, int lower_only, double jitter,
+                                                        int symmetric, int lower_only, int accumulate, double jitter,
                                                         T* __restrict__ K, long ldk) {
     const int tc = blockIdx.x, tr = blockIdx.y;
     // symmetric builds evaluate only tiles on/below the diagonal; lower_only == 0 also writes the mirror image
@@ -143,12 +144,14 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
             for (int e = 0; e < VE; ++e) {
                 const int gj = tc * KT + v * (16 * VE) + tx * VE + e;
                 T val = out[r][v * VE + e];
-                if (gi >= nr || gj >= nc) val = (symmetric && gi == gj) ? (T)1 : (T)0;
+                if (gi >= nr || gj >= nc) val = (symmetric && gi == gj && !accumulate) ? (T)1 : (T)0;
                 else if (symmetric && gi == gj) val += (T)dg;
                 vec[e] = val;
                 if (mirror) tt[(v * (16 * VE) + tx * VE + e) * TLD + ty * 4 + r] = val;
             }
-            *reinterpret_cast<typename VecOf<T>::type*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE) = vec;
+            typename VecOf<T>::type* dst = reinterpret_cast<typename VecOf<T>::type*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE);
+            if (accumulate) vec += *dst;    // a further pass of a Compose with more than PG_MAX_COMP children
+            *dst = vec;
         }
     }
     if (mirror) {   // K[tc-tile rows][tr-tile cols] = transpose, read back row-wise so the stores stay 256-byte runs
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                 typename VecOf<T>::type vec;
 #pragma unroll
                 for (int e = 0; e < VE; ++e) vec[e] = tt[li * TLD + v * (16 * VE) + tx * VE + e];
-                *reinterpret_cast<typename VecOf<T>::type*>(K + (long)(tc * KT + li) * ldk + tr * KT + v * (16 * VE) + tx * VE) = vec;
+                typename VecOf<T>::type* dst = reinterpret_cast<typename VecOf<T>::type*>(K + (long)(tc * KT + li) * ldk + tr * KT + v * (16 * VE) + tx * VE);
+                if (accumulate) vec += *dst;
+                *dst = vec;
             }
         }
     }
@@ -169,23 +174,30 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
 
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
-              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, double jitter, T* K,
+              const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,
               long ldk, int rows_pad, int cols_pad) {
     if (rows_pad % KT || cols_pad % KT || d < 1 || d > PG_MAX_DIM) {
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
     }
     const size_t lds = (size_t)(2 * KT * d + PG_MAX_COMP * d + (symmetric && !lower_only ? KT * TLD : 0)) * sizeof(T);
+    static bool attr_done = false;
+    if (!attr_done) {   // the mirrored fp64 build passes the 64 KB a kernel gets without opting in from d = 31 (101 KB at d = 64)
+        const size_t lds_max = (size_t)(2 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + KT * TLD) * sizeof(T);
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_done = true;
+    }
     dim3 grid(cols_pad / KT, rows_pad / KT);
     hipLaunchKernelGGL(pg_kbuild_kernel<T>, grid, dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                       symmetric, lower_only, jitter, K, ldk);
+                       symmetric, lower_only, accumulate, jitter, K, ldk);
     PG_CHECK(hipGetLastError());
     return 0;
 }
 template int pg_kbuild<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int,
-                               const double*, long, int, int, int, int, double, double*, long, int, int);
+                               const double*, long, int, int, int, int, int, double, double*, long, int, int);
 template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int,
-                              const float*, long, int, int, int, int, double, float*, long, int, int);
+                              const float*, long, int, int, int, int, int, double, float*, long, int, int);
 
 // ------------------------------------------------------------------------------------------------
 // dK stack of the public Covar.kernel_and_grad (covar.py:64-81,169-206,247-269): dK[p][i][j] for
@@ -250,11 +262,10 @@ template int pg_kgrad<float>(hipStream_t, const pg_covspec&, const double*, cons
 template <typename T>
 __global__ __launch_bounds__(256) void pg_centres_kernel(const T* __restrict__ X, long ldx, int n, const T* __restrict__ Cn,
                                                          long ldc, int m, int d, T* __restrict__ D, long ldd,
-                                                         int* __restrict__ idx) {
+                                                         int* __restrict__ idx, int chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* cs = reinterpret_cast<T*>(smem_raw);          // [chunk][d]
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int chunk = min(m, 1024);
     T best = (T)0;
     int arg = 0;
     for (int j0 = 0; j0 < m; j0 += chunk) {
@@ -280,8 +291,11 @@ __global__ __launch_bounds__(256) void pg_centres_kernel(const T* __restrict__ X
 template <typename T>
 int pg_centres(hipStream_t st, const T* X, long ldx, int n, const T* Cn, long ldc, int m, int d, T* D, long ldd, int* idx) {
     if (n <= 0 || m <= 0 || d < 1 || d > PG_MAX_DIM) { pg_set_error("pg_sqdist: bad shape n=%d m=%d d=%d", n, m, d); return -2; }
-    const size_t lds = (size_t)std::min(m, 1024) * d * sizeof(T);
-    hipLaunchKernelGGL(pg_centres_kernel<T>, dim3((n + 255) / 256), dim3(256), lds, st, X, ldx, n, Cn, ldc, m, d, D, ldd, idx);
+    // centres are staged in chunks that fit the 64 KB of LDS a kernel gets without opting in, whatever d is
+    const int chunk = std::max(1, std::min(std::min(m, 1024), (int)(48 * 1024 / (d * sizeof(T)))));
+    const size_t lds = (size_t)chunk * d * sizeof(T);
+    hipLaunchKernelGGL(pg_centres_kernel<T>, dim3((n + 255) / 256), dim3(256), lds, st, X, ldx, n, Cn, ldc, m, d, D, ldd, idx,
+                       chunk);
     PG_CHECK(hipGetLastError());
     return 0;
 }
@@ -423,16 +437,19 @@ __global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, co
     if (tid == 0) {
         s = red[0] + red[1] + red[2] + red[3];
         double scale = 0.0;
+        bool mine = false;   // entries of children that are not in this spec belong to another pass of a long Compose
         for (int c = 0; c < spec.ncomp; ++c) {
             const int o = spec.off[c];
-            if (p == o) scale = 0.5 * 2.0 / hp[o];                        // dK/dsigma = 2K/sigma
-            else if (p > o && p <= o + d)
+            if (p == o) { scale = 0.5 * 2.0 / hp[o]; mine = true; }       // dK/dsigma = 2K/sigma
+            else if (p > o && p <= o + d) {
                 scale = (spec.kind[c] == PG_KIND_RBF) ? 0.5 * -2.0 * hp[p]   // -2 l_k D_k^2 K
                                                       : 0.5 * -(5.0 / 3.0) * hp[p];
+                mine = true;
+            }
         }
         for (int i = 0; i < spec.nnoise; ++i)
-            if (p == spec.noise_off[i]) scale = 0.5 * 2.0 * hp[p];        // dK/dsigma_n = 2 sigma_n I
-        grad[p] = scale * s;
+            if (p == spec.noise_off[i]) { scale = 0.5 * 2.0 * hp[p]; mine = true; }   // dK/dsigma_n = 2 sigma_n I
+        if (mine) grad[p] = scale * s;
     }
 }
 

@@ -82,12 +82,19 @@ class GPR:
         raise NotImplementedError
 
 
+class _Data:
+    """Device copy of one (x, y) pair: x [n, d], y zero-padded to n_pad."""
+
+    __slots__ = ("x", "y", "n", "n_pad")
+
+
 class _Expert:
-    """Device state of one expert."""
+    """Device state of one expert (its data may be shared with other experts: batched params on unbatched x)."""
 
     __slots__ = ("x", "y", "n", "n_pad", "chol", "invd", "alpha", "minv", "minv_valid", "work", "hp", "info")
 
-    def __init__(self):
+    def __init__(self, data):
+        self.x, self.y, self.n, self.n_pad = data.x, data.y, data.n, data.n_pad
         self.chol = self.invd = self.alpha = self.minv = self.work = self.hp = self.info = None
         self.minv_valid = False
 
@@ -99,6 +106,8 @@ class Exact_GP(GPR):
         super().__init__(x, y, cov)
         self.params: Tensor = cov.init_params(x)
         self._experts = None
+        self._data = None
+        self._data_key = None
         self.need_upd: bool = True
         # eager_inverse: form L^-1 inside update() (fused with the Cholesky) and take alpha = L^-T (L^-1 y) from two
         # triangular mat-vecs.  Worth it whenever predictive variances follow (grBCM experts); wasted work otherwise.
@@ -112,28 +121,51 @@ class Exact_GP(GPR):
 
     @property
     def batched(self) -> bool:
-        return self._x.dim() > 2
+        """More than one expert: the reference's kernels squeeze a batch of one away (covar.py:161-165), so x [1, n, d]
+        behaves like x [n, d]."""
+        return len(self._device_experts()) > 1
 
     def _data_changed(self) -> None:
         self._experts = None
+        self._data = None
         self.need_upd = True
 
-    def _device_experts(self):
-        """Upload x / y once (padded y), one _Expert per leading index."""
-        if self._experts is None:
+    def _device_data(self):
+        """x / y on the device, one _Data per leading index of x, uploaded once per (tensor identity, version): in-place
+        edits of model.x / model.y (`model.y.copy_(new)`) are seen by the next evaluation, as in the reference, which
+        re-reads model.x / model.y on every call (loss.py:37,43)."""
+        key = (id(self._x), self._x._version, id(self._y), self._y._version)
+        if self._data is None or self._data_key != key:
             ops = get_ops()
             xb = self._x.reshape(-1, self._x.shape[-2], self._x.shape[-1])
             yb = self._y.reshape(-1, self._y.shape[-1])
-            ex = []
-            for b in range(xb.shape[0]):
-                e = _Expert()
-                e.n = xb.shape[1]
-                e.n_pad = pad_to(e.n)
-                e.x = ops.to_device(xb[b], self.dtype)
-                e.y = ops.zeros(e.n_pad, dtype=self.dtype)
-                e.y[: e.n] = ops.to_device(yb[b % yb.shape[0]], self.dtype)
-                ex.append(e)
-            self._experts = ex
+            nbd = max(xb.shape[0], yb.shape[0])
+            if xb.shape[0] not in (1, nbd) or yb.shape[0] not in (1, nbd):
+                raise RuntimeError("batch dimensions of x and y do not broadcast")
+            xs = [ops.to_device(xb[b], self.dtype) for b in range(xb.shape[0])]
+            data = []
+            for b in range(nbd):
+                dt = _Data()
+                dt.n = xb.shape[1]
+                dt.n_pad = pad_to(dt.n)
+                dt.x = xs[b % len(xs)]
+                dt.y = ops.zeros(dt.n_pad, dtype=self.dtype)
+                dt.y[: dt.n] = ops.to_device(yb[b % yb.shape[0]], self.dtype)
+                data.append(dt)
+            self._data, self._data_key = data, key
+            self._experts = None
+        return self._data
+
+    def _device_experts(self):
+        """One _Expert per model of the batch: max(batch of x / y, batch of params) of them, as cov.kernel(params, x)
+        broadcasts in the reference (gpr.py:67; params [nc, nhp] on an unbatched x are nc models on the same points)."""
+        data = self._device_data()
+        nb = max(len(data), self._hp_rows().shape[0])
+        if len(data) not in (1, nb) or self._hp_rows().shape[0] not in (1, nb):
+            raise RuntimeError("batch dimensions of params and x do not broadcast")
+        if self._experts is None or len(self._experts) != nb:
+            self._experts = [_Expert(data[b % len(data)]) for b in range(nb)]
+            self.need_upd = True
         return self._experts
 
     def _hp_rows(self):
@@ -236,11 +268,17 @@ class Exact_GP(GPR):
         return c[:m, :m]
 
     def _predict_device(self, xpd, want):
-        """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points."""
+        """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points: xpd [m, d]
+        (the same points for every expert) or [nc, m, d] (expert b predicts at xpd[b], as cov.kernel(params, x, xp)
+        broadcasts in the reference, gpr.py:79)."""
+        self._device_experts()
         self.update()
+        if xpd.dim() == 3 and xpd.shape[0] not in (1, len(self._experts)):
+            raise RuntimeError("batch dimension of xp (%d) does not match the %d experts" % (xpd.shape[0], len(self._experts)))
         means, covs = [], []
         for b, e in enumerate(self._experts):
-            mu, cv = self._predict_expert(b, e, xpd, want)
+            xq = xpd if xpd.dim() == 2 else xpd[b % xpd.shape[0]]
+            mu, cv = self._predict_expert(b, e, xq, want)
             means.append(mu)
             covs.append(cv)
         return means, covs
@@ -248,7 +286,7 @@ class Exact_GP(GPR):
     def predict(self, xp: Tensor, var: str = "full") -> Sequence[Tensor]:
         ops = get_ops()
         want = var if var in ("full", "diag") else "none"
-        xpd = ops.to_device(xp.reshape(-1, xp.shape[-1]), self.dtype)
+        xpd = ops.to_device(xp if xp.dim() == 2 else xp.reshape(-1, xp.shape[-2], xp.shape[-1]), self.dtype)
         means, covs = self._predict_device(xpd, want)
         ys = torch.stack(means).squeeze().to(xp.device)   # squeeze_(): drops every size-1 dim (gpr.py:87)
         if want == "none":
@@ -297,6 +335,7 @@ class Exact_GP(GPR):
 
     @property
     def wt(self) -> Tensor:
-        """alpha = K^-1 y (gpr.py:70-72)."""
+        """alpha = K^-1 y (gpr.py:70-72): cholesky_solve(y[..., None], L) keeps y's leading dimensions."""
         self.update()
-        return self._stack([e.alpha[: e.n] for e in self._experts])
+        out = self._stack([e.alpha[: e.n] for e in self._experts])
+        return out.reshape(self._y.shape) if (not self.batched and self._y.dim() > 1) else out

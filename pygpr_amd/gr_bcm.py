@@ -280,7 +280,7 @@ class GRBCM_MLE(Loss):
                 loss, grad = self._mle._evaluate(rows, want_grad)
                 vec[0] = np.sum(loss)
                 if want_grad:
-                    vec[1: 1 + nhp] = np.sum(grad, axis=0)
+                    vec[1: 1 + nhp] = np.sum(np.atleast_2d(grad), axis=0)
             except torch.linalg.LinAlgError as err:
                 if not self.model.distributed:
                     raise
@@ -308,3 +308,11 @@ class GRBCM_MLE(Loss):
         vec = self._local(params, True)
         self.loss_value, self.grad_value = np.array(vec[0]), vec[1:].copy()
         return (self.loss_value, self.grad_value)
+
+
+def log_likelihood_batched(*args, **kwargs):
+    """Exported by the reference (PyGPR/__init__.py:5) but dead there: gr_bcm.py:158-176 calls a covariance object as a
+    function and has a dangling `+` ("dead" row).  Kept as a name so that
+    `from PyGPR import log_likelihood_batched` style imports keep working; the batched NLML is `MLE(model).loss`."""
+    raise NotImplementedError("log_likelihood_batched is legacy code that cannot run in the reference either "
+                              "(gr_bcm.py:158-176); use MLE(model).loss / GRBCM_MLE(model).loss")

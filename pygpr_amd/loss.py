@@ -16,7 +16,7 @@ import torch
 from numpy import ndarray
 
 from ._ops import JITTER, get_ops
-from .covar import spec_of
+from .covar import layout, spec_of
 from .gpr import GPR, _lin_alg_error
 
 
@@ -47,6 +47,7 @@ class MLE(Loss):
         self._buf = {}
         self.memoize = True     # re-use the last evaluation when asked again at identical parameters (off in benchmarks)
         self._memo = None
+        self._factor_key = None   # memo key of the loss-only evaluation whose factor is still in the work buffers
 
     def _buffers(self, n_pad, dtype, nhp, n):
         key = (n_pad, dtype, nhp, n)
@@ -67,17 +68,24 @@ class MLE(Loss):
         return self._buf
 
     def _evaluate(self, params: ndarray, want_grad: bool):
-        """One evaluation, memoised on (parameters, data identity): the reference re-factorises on every call
-        (loss.py:39,64,97); CG_Quad / BFGS_Quad / hessian ask for grad(par) at the same point again and again."""
-        key = (np.asarray(params, dtype=np.float64).tobytes(), np.shape(params), id(self.model._x), id(self.model._y))
+        """One evaluation, memoised on (parameters, data identity and version, covariance): the reference re-factorises on
+        every call (loss.py:39,64,97); CG_Quad / BFGS_Quad / hessian ask for grad(par) at the same point again and again,
+        and get_learn_rate / Nelder_Mead callers ask for loss(p) and then grad(p).  Two levels:
+          * the last RESULT is returned as is when it already holds what is asked for;
+          * after a loss-only evaluation of a single model the FACTOR stays in the work buffers: a following grad(p) at
+            the same p only adds L^-1, K^-1 and the contraction (no second covariance build / Cholesky)."""
+        m = self.model      # the reference re-reads model.x / .y / .cov on every call: all three are part of the key
+        key = (np.asarray(params, dtype=np.float64).tobytes(), np.shape(params), id(m._x), m._x._version, id(m._y), m._y._version,
+               id(m.cov), tuple(map(tuple, layout(m.cov, m._x.shape[-1])[:3])))
         hit = self._memo if (self.memoize and self._memo is not None and self._memo[0] == key) else None
         if hit is not None and (hit[2] is not None or not want_grad):
             return hit[1].copy(), (hit[2].copy() if hit[2] is not None else None)
-        loss, grad = self._evaluate_device(params, want_grad)
+        reuse = hit is not None and want_grad and self._factor_key == key
+        loss, grad = self._evaluate_device(params, want_grad, key if self.memoize else None, reuse)
         self._memo = (key, loss.copy(), grad.copy() if want_grad else None)
         return loss, grad
 
-    def _evaluate_device(self, params: ndarray, want_grad: bool):
+    def _evaluate_device(self, params: ndarray, want_grad: bool, key=None, reuse_factor=False):
         ops = get_ops()
         model = self.model
         d = model.x.shape[-1]
@@ -85,20 +93,29 @@ class MLE(Loss):
         p = np.asarray(params, dtype=np.float64)
         assert p.shape[-1] == nhp  # covar.py:52,66
         rows = p.reshape(-1, nhp)
-        experts = model._device_experts()
+        experts = model._device_data()      # one (x, y) per leading index of the data; the batch of params broadcasts
+        if len(experts) not in (1, rows.shape[0]) and rows.shape[0] != 1:
+            raise RuntimeError("batch dimensions of params and x do not broadcast")
         nb = max(len(experts), rows.shape[0])
         losses = np.empty(nb)
         grads = np.empty((nb, nhp))
+        self._factor_key = None             # whatever the buffers held is overwritten below
         for b in range(nb):
             e = experts[b % len(experts)]
             buf = self._buffers(e.n_pad, model.dtype, nhp, e.n)
             hp = ops.to_device(torch.from_numpy(np.array(rows[b % rows.shape[0]], dtype=np.float64)), torch.float64)
             a, out = buf["a"], buf["out"]
-            ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
-            if want_grad:
-                if buf["m"] is None:
-                    buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
-                m = buf["m"]
+            if want_grad and buf["m"] is None:
+                buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
+            m = buf["m"]
+            if reuse_factor and nb == 1:
+                # `a` still holds the factor and buf["alpha"] the weights of the loss-only evaluation at these parameters
+                ops.trtri(a, buf["invd"], m)
+                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
+                ops.lauum(m, a)
+                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
+            elif want_grad:
+                ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
                 ops.potrf_trtri(a, buf["invd"], buf["info"], m)      # Cholesky + L^-1, overlapped inside the library
                 ops.trmv(m, e.y, buf["u"], 0)                       # u = L^-1 y
                 ops.trmv(m, buf["u"], buf["alpha"], 1, buf["vwork"])  # alpha = L^-T u
@@ -106,6 +123,7 @@ class MLE(Loss):
                 ops.lauum(m, a)                                     # a <- K^-1 (lower)
                 ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
             else:
+                ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
                 ops.potrf(a, buf["invd"], buf["info"])
                 ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
                 ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
@@ -115,7 +133,9 @@ class MLE(Loss):
                 raise _lin_alg_error(info)
             losses[b] = res[0]
             grads[b] = res[1:]
-        batched = p.ndim > 1 or model.x.dim() > 2
+        if not want_grad and nb == 1 and key is not None:
+            self._factor_key = key
+        batched = nb > 1      # a batch of one is squeezed away (llhd.squeeze_(0), loss.py:51,85,111)
         loss = losses.copy() if batched else np.array(losses[0])
         grad = grads.copy() if batched else grads[0].copy()
         return loss, grad

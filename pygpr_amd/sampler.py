@@ -112,3 +112,9 @@ class MATERN1(UNIFORM):
     def partition(self, nc, ns, mins, maxs):
         xc = self.sample(nc, mins, maxs)
         return self.cluster_samples(xc, ns, mins, maxs), xc
+
+
+def sample_gp(*args, **kwargs):
+    """Exported by the reference (PyGPR/__init__.py:6) but dead there: sampler.py:122-137 calls `cov(x)` on objects that
+    are not callable ("dead" row).  Kept as a name for import compatibility."""
+    raise NotImplementedError("sample_gp is legacy code that cannot run in the reference either (sampler.py:122-137)")

@@ -16,10 +16,16 @@ def _np(t):
     return t.detach().numpy()
 
 
+def _passes(spec):
+    return spec if isinstance(spec, (list, tuple)) else [spec]
+
+
 def _covs(spec, hp, d):
-    """(kind, hp slice) list from a pg_covspec."""
-    comps = [("se" if spec.kind[c] == 0 else "matern52", hp[spec.off[c]: spec.off[c] + d + 1]) for c in range(spec.ncomp)]
-    noise = [hp[spec.noise_off[i]] for i in range(spec.nnoise)]
+    """(kind, hp slice) list from a pg_covspec or the list of passes of a long Compose."""
+    comps, noise = [], []
+    for sp in _passes(spec):
+        comps += [({0: "se", 1: "matern52", 2: "sqdist"}[sp.kind[c]], hp[sp.off[c]: sp.off[c] + d + 1]) for c in range(sp.ncomp)]
+        noise += [hp[sp.noise_off[i]] for i in range(sp.nnoise)]
     return comps, noise
 
 
@@ -28,6 +34,8 @@ def _k(comps, xr, xc):
     for kind, h in comps:
         if kind == "se":
             out += orc.se_kernel(h, xc, xr, form="direct")
+        elif kind == "sqdist":
+            out += (((xr[:, None, :] - xc[None, :, :]) * h[1:]) ** 2).sum(2)
         else:
             out += orc.matern52_kernel(h, xc, xr)
     return out
@@ -71,12 +79,21 @@ class OracleOps:
         d = xx.shape[1]
         o = _np(out)
         o[...] = 0.0
-        for c in range(spec.ncomp):
-            sl = slice(spec.off[c], spec.off[c] + d + 1)
-            fn = orc.se_kernel_and_grad if spec.kind[c] == 0 else orc.matern52_kernel_and_grad
-            o[sl] = fn(h[sl], xx, **({"form": "direct"} if spec.kind[c] == 0 else {}))[1]
-        for i in range(spec.nnoise):
-            o[spec.noise_off[i]] = 2.0 * h[spec.noise_off[i]] * np.eye(xx.shape[0])
+        for sp in _passes(spec):
+            for c in range(sp.ncomp):
+                sl = slice(sp.off[c], sp.off[c] + d + 1)
+                fn = orc.se_kernel_and_grad if sp.kind[c] == 0 else orc.matern52_kernel_and_grad
+                o[sl] = fn(h[sl], xx, **({"form": "direct"} if sp.kind[c] == 0 else {}))[1]
+            for i in range(sp.nnoise):
+                o[sp.noise_off[i]] = 2.0 * h[sp.noise_off[i]] * np.eye(xx.shape[0])
+        return out
+
+    def sqdist(self, xr, xc, out):
+        a = _np(xr).astype(np.float64)
+        b = a if xc is None else _np(xc).astype(np.float64)
+        o = _np(out)
+        o[...] = np.eye(o.shape[0], o.shape[1]) if xc is None else 0.0
+        o[: a.shape[0], : b.shape[0]] = ((a[:, None, :] - b[None, :, :]) ** 2).sum(2)
         return out
 
     # factorisation

@@ -176,6 +176,97 @@ def test_kernel_build(ops, covs, n, d):
         assert (gl[:64, 64:128] == -7.0).all()
 
 
+@pytest.mark.parametrize("d", [31, 48, 64])
+def test_kernel_build_large_d(ops, d):
+    """From d = 31 the mirrored fp64 build needs more than the 64 KB of LDS a kernel gets without opting in (101 KB at
+    d = 64 = PG_MAX_DIM): full, lower-only and cross builds, and the NLML gradient at the same d, against the oracle."""
+    from pygpr_amd._ops import pad_to
+
+    rng = np.random.default_rng(d)
+    n, m = 200, 70
+    covs = [orc.SE, orc.WN]
+    x, xp = rng.random((n, d)), rng.random((m, d))
+    hp = np.concatenate([[1.1], (0.2 + 0.3 * rng.random(d)) / np.sqrt(d), [0.1]])
+    spec, npad, mpad = _spec(covs, d), pad_to(n), pad_to(m)
+    hpd, xd, xpd = dev(hp), dev(x), dev(xp)
+    ref = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(spec, hpd, xd, None, k, jitter=1e-7)
+    got = host(k)
+    np.testing.assert_allclose(got[:n, :n], ref, atol=1e-14, rtol=1e-14)
+    assert np.array_equal(got, got.T) and np.array_equal(got[n:, n:], np.eye(npad - n))
+    kl = ops.zeros(npad, npad) - 7.0
+    ops.kernel_build(spec, hpd, xd, None, kl, lower_only=True, jitter=1e-7)
+    np.testing.assert_array_equal(np.tril(host(kl)), np.tril(got))
+    assert (host(kl)[:64, 64:128] == -7.0).all()
+    ks = ops.empty(npad, mpad)
+    ops.kernel_build(spec, hpd, xd, xpd, ks)
+    np.testing.assert_allclose(host(ks)[:n, :m], orc.kernel(covs, hp, x, xp, form="direct").T, atol=1e-14, rtol=1e-14)
+    kf = ops.empty(npad, npad, dtype=torch.float32)
+    ops.kernel_build(spec, hpd, dev(x, torch.float32), None, kf, jitter=1e-7)
+    np.testing.assert_allclose(host(kf)[:n, :n], ref, atol=5e-6)
+
+
+def test_kernel_build_passes_accumulate(ops):
+    """A Compose with more children than one pg_covspec holds is evaluated in passes (make_specs): the first pass writes,
+    later ones accumulate and leave the padding alone; gradient passes fill disjoint entries."""
+    from pygpr_amd._ops import make_specs, pad_to
+    from pygpr_amd._lib import PG_KIND_MATERN52, PG_KIND_RBF
+
+    rng = np.random.default_rng(3)
+    n, d = 150, 3
+    covs = [orc.SE, orc.WN, orc.M52, orc.SE, orc.WN, orc.WN, orc.SE, orc.WN, orc.SE, orc.M52, orc.WN]
+    kinds, offs, noise, o = [], [], [], 0
+    for c in covs:
+        if c.kind == "wn":
+            noise.append(o); o += 1
+        else:
+            kinds.append(PG_KIND_RBF if c.kind == "se" else PG_KIND_MATERN52); offs.append(o); o += d + 1
+    specs = make_specs(kinds, offs, noise)
+    assert len(specs) == 2
+    hp = np.concatenate([0.4 + 0.4 * rng.random(c.nhp(d)) if c.kind != "wn" else 0.05 + 0.1 * rng.random(1) for c in covs])
+    x, y = rng.random((n, d)), rng.standard_normal(n)
+    npad = pad_to(n)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(specs, dev(hp), dev(x), None, k, jitter=1e-7)
+    got = host(k)
+    np.testing.assert_allclose(got[:n, :n], orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n), atol=1e-13)
+    assert np.array_equal(got[n:, n:], np.eye(npad - n)) and not got[n:, :n].any()
+    ks = ops.empty(npad, 256)
+    xp = rng.random((40, d))
+    ops.kernel_build(specs, dev(hp), dev(x), dev(xp), ks)
+    np.testing.assert_allclose(host(ks)[:n, :40], orc.kernel(covs, hp, x, xp, form="direct").T, atol=1e-13)
+    # gradient through the passes, against the oracle's K^-1 route
+    kd = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    kinv = np.linalg.inv(kd)
+    alpha = kinv @ y
+    kpad = np.eye(npad); kpad[:n, :n] = kinv
+    apad = np.zeros(npad); apad[:n] = alpha
+    grad = ops.zeros(hp.size)
+    work = ops.empty(ops.nlml_grad_worksize(n, hp.size))
+    ops.nlml_grad(specs, dev(hp), dev(x), n, dev(kpad), dev(apad), grad, work)
+    _, gref = orc.mle_loss_and_grad(covs, hp, x, y, "kinv", form="direct")
+    np.testing.assert_allclose(host(grad), gref, rtol=1e-8, atol=1e-8 * np.abs(gref).max())
+
+
+def test_sqdist_kind_and_centres_any_d(ops):
+    """PG_KIND_SQDIST through the covariance tile kernel (Squared_exponential.distance), and pg_sqdist_argmin with more
+    centres x dimensions than 64 KB of LDS holds at once (m = 1500, d = 16 in fp64; d = 64)."""
+    rng = np.random.default_rng(8)
+    x, c = rng.random((300, 5)), rng.random((90, 5))
+    out = ops.empty(320, 128)
+    ops.sqdist(dev(x), dev(c), out)
+    np.testing.assert_allclose(host(out)[:300, :90], ((x[:, None, :] - c[None, :, :]) ** 2).sum(2), atol=1e-14)
+    for m, d in ((1500, 16), (200, 64)):
+        x, c = rng.random((700, d)), rng.random((m, d))
+        d2 = ((x[:, None, :] - c[None, :, :]) ** 2).sum(2)
+        dist = ops.empty(700, m)
+        idx = torch.zeros(700, dtype=torch.int32, device="cuda")
+        ops.sqdist_argmin(dev(x), dev(c), dist, idx)
+        np.testing.assert_allclose(host(dist), d2, atol=1e-12)
+        assert np.array_equal(idx.cpu().numpy(), np.argmin(d2, axis=1))
+
+
 def test_kernel_build_fp32(ops):
     from pygpr_amd._ops import pad_to
 

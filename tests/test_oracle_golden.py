@@ -180,3 +180,39 @@ def test_as_written_torch_baseline_matches_solve_route():
     assert abs(f0 - f1) <= 1e-11 * abs(f0) and abs(f0 - f2) <= 1e-11 * abs(f0)
     np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
     np.testing.assert_allclose(g2, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
+
+
+def test_oracle_round2_surface_fixtures(golden):
+    """Pins the oracle to the round-2 fixtures (make_golden_r2.py): distance, an 11-child Compose, batched test points,
+    batched params on shared points."""
+    g = golden("surface2")
+    np.testing.assert_allclose(orc.se_distance(g["d_x"]), g["d_sq"], atol=1e-15)
+    np.testing.assert_allclose(orc.se_distance(g["d_x"], g["d_xp"]), g["d_sqp"], atol=1e-15)
+    np.testing.assert_allclose(orc.se_distance(g["d_x"], g["d_xp"], form="direct"), g["d_sqp"], atol=1e-14)
+    for c in range(3):
+        np.testing.assert_allclose(orc.se_distance(g["d_xb"][c], g["d_xpb"][c]), g["d_sqpb"][c], atol=1e-15)
+    covs = covs_of(g["L_kinds"])
+    k, dk = orc.kernel_and_grad(covs, g["L_hp"], g["L_x"])
+    np.testing.assert_allclose(k, g["L_k"], atol=1e-14)
+    np.testing.assert_allclose(dk, g["L_dk"], atol=1e-13)
+    np.testing.assert_allclose(orc.kernel(covs, g["L_hp"], g["L_x"], g["L_xp"]), g["L_ks"], atol=1e-14)
+    mu, var = orc.gp_predict(covs, g["L_hp"], g["L_x"], g["L_y"], g["L_xp"], "diag")
+    np.testing.assert_allclose(mu, g["L_mu"], atol=1e-11)
+    np.testing.assert_allclose(var, g["L_var"], atol=1e-12)
+    for route in ("solve", "kinv"):
+        l, gr = orc.mle_loss_and_grad(covs, g["L_hp"], g["L_x"], g["L_y"], route)
+        np.testing.assert_allclose(l, g["L_loss"], rtol=1e-11)
+        np.testing.assert_allclose(gr, g["L_grad"], rtol=1e-8, atol=1e-8 * np.abs(g["L_grad"]).max())
+    sw = [orc.SE, orc.WN]
+    for c in range(3):
+        mu, var = orc.gp_predict(sw, g["bx_hp"][c], g["bx_x"][c], g["bx_y"][c], g["bx_xp"][c], "diag")
+        np.testing.assert_allclose(mu, g["bx_mu"][c], atol=1e-11)
+        np.testing.assert_allclose(var, g["bx_var"][c], atol=1e-12)
+        _, cov = orc.gp_predict(sw, g["bx_hp"][c], g["bx_x"][c], g["bx_y"][c], g["bx_xp"][c], "full")
+        np.testing.assert_allclose(cov, g["bx_cov"][c], atol=1e-12)
+    for c in range(4):
+        mu, var = orc.gp_predict(sw, g["bp_hp"][c], g["bp_x"], g["bp_y"], g["bp_xp"], "diag")
+        np.testing.assert_allclose(mu, g["bp_mu"][c], atol=1e-11)
+        np.testing.assert_allclose(orc.mle_loss(sw, g["bp_hp"][c], g["bp_x"], g["bp_y"]), g["bp_loss"][c], rtol=1e-11)
+    _, chol, _ = orc.gp_update([orc.SE], g["r1_hp"], g["r1_x"], g["r1_y"])     # the rank-one covariance factorises
+    np.testing.assert_allclose(chol, g["r1_krnchd"], rtol=1e-7, atol=1e-12)

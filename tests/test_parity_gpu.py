@@ -181,7 +181,8 @@ def test_exact_gp_properties(n, nc):
 
 def test_not_positive_definite_raises():
     """torch.cholesky raises torch.linalg.LinAlgError (a RuntimeError) naming the failing leading minor
-    (SURVEY 5 / 8b); a NaN hyper-parameter makes the very first pivot fail."""
+    (SURVEY 5 / 8b); a NaN hyper-parameter makes the very first pivot fail.  (The rank-one covariance round 1 first
+    tried here is factorised by the reference too -- fixture r1_* of surface2.npz, check_rank_one_covariance.)"""
     x = torch.rand(40, 2, dtype=torch.float64)
     gp = pg.Exact_GP(x, torch.rand(40, dtype=torch.float64), se_wn())
     gp.set_params(torch.tensor([float("nan"), 1.0, 1.0, 0.1], dtype=torch.float64))
@@ -428,6 +429,98 @@ def test_cfg2_size_properties():
     mu, _ = gp.predict(T(x[:2048]), var="none")
     alpha = N(gp.wt)
     np.testing.assert_allclose(N(mu), y[:2048] - (hp[-1] ** 2 + 1e-7) * alpha[:2048], atol=1e-8)
+
+
+@pytest.mark.parametrize("case", __import__("surface_cases").ALL, ids=lambda f: f.__name__)
+def test_surface_round2(golden, case):
+    """distance(), an 11-child Compose, batched test points, batched params on shared points, batch-of-one squeezes, the
+    rank-one covariance the reference factorises, memo invalidation -- against fixtures captured from the reference."""
+    case(golden("surface2"))
+
+
+def test_large_d_through_the_class_surface():
+    """d = 40 and d = 64 (PG_MAX_DIM): cov.kernel (mirrored build), predict(var="full") (K** mirrored build) and the
+    NLML gradient against the oracle."""
+    for d in (40, 64):
+        n, m = 300, 33
+        rng = np.random.default_rng(d)
+        x, xp = rng.random((n, d)), rng.random((m, d))
+        y = np.sin(-x.sum(1)) + 0.1 * rng.standard_normal(n)
+        hp = np.concatenate([[1.0], (0.3 + 0.3 * rng.random(d)) / np.sqrt(d), [0.1]])
+        covs = [orc.SE, orc.WN]
+        np.testing.assert_allclose(N(se_wn().kernel(T(hp), T(x))), orc.kernel(covs, hp, x), atol=1e-13)
+        gp = pg.Exact_GP(T(x), T(y), se_wn())
+        gp.set_params(T(hp))
+        mu, cov = gp.predict(T(xp), var="full")
+        mu_r, cov_r = orc.gp_predict(covs, hp, x, y, xp, "full")
+        np.testing.assert_allclose(N(mu), mu_r, atol=1e-9)
+        np.testing.assert_allclose(N(cov), cov_r, atol=1e-10)
+        loss, grad = pg.MLE(gp).loss_and_grad(hp.copy())
+        l_r, g_r = orc.mle_loss_and_grad(covs, hp, x, y, "kinv")
+        np.testing.assert_allclose(loss, l_r, rtol=1e-10)
+        np.testing.assert_allclose(grad, g_r, rtol=1e-8, atol=1e-8 * np.abs(g_r).max())
+
+
+def test_headline_size_properties():
+    """BASELINE config 3's size, N=16384 D=8 fp64 -- the NBO = 1024 schedule with the background split that bench.py
+    times (16 outer panels): (i) directional derivative against central differences, (ii) K alpha = y through a
+    prediction at training inputs, (iii) the fused pg_potrf_trtri factor equals the separate pg_potrf bit for bit and
+    its inverse undoes it."""
+    from pygpr_amd._ops import get_ops
+
+    n, d = 16384, 8
+    x, y = orc.synth(n, d, seed=1234)
+    hp = np.concatenate([[1.0], np.ones(d), [0.1]])
+    gp = pg.Exact_GP(T(x), T(y), se_wn())
+    mle = pg.MLE(gp)
+    mle.memoize = False
+    loss, grad = mle.loss_and_grad(hp.copy())
+    assert np.isfinite(loss) and np.isfinite(grad).all()
+    v = np.random.default_rng(0).standard_normal(hp.size)
+    v /= np.linalg.norm(v)
+    eps = 1e-5
+    fd = (mle.loss(hp + eps * v) - mle.loss(hp - eps * v)) / (2 * eps)
+    np.testing.assert_allclose(grad @ v, fd, rtol=2e-5)
+    gp.set_params(T(hp))
+    mu, _ = gp.predict(T(x[:1024]), var="none")
+    alpha = N(gp.wt)
+    np.testing.assert_allclose(N(mu), y[:1024] - (hp[-1] ** 2 + 1e-7) * alpha[:1024], atol=2e-8)
+    del gp, mle
+    torch.cuda.empty_cache()
+    ops = get_ops()
+    spec, _ = pg.covar.spec_of(se_wn(), d)
+    xd, hpd = T(x).cuda(), T(hp).cuda()
+    a, b = ops.empty(n, n), ops.empty(n, n)
+    ops.kernel_build(spec, hpd, xd, None, a, lower_only=True, jitter=1e-7)
+    b.copy_(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd, invd2 = ops.potrf_workspace(n, torch.float64), ops.potrf_workspace(n, torch.float64)
+    minv = ops.empty(n, n)
+    ops.potrf_trtri(a, invd, info, minv)
+    assert int(info.item()) == 0
+    ops.potrf(b, invd2, info)
+    assert torch.equal(torch.tril(a), torch.tril(b))
+    del b
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+    low = torch.tril(a)
+    assert float((torch.tril(minv) @ (low @ w) - w).abs().max()) <= 1e-8
+
+
+def test_cfg5_size_fp32_tracks_fp64():
+    """BASELINE config 5's per-expert size, n = 33792 (NBO = 2048 with the background split), Matern-5/2, D = 16: the fp32
+    NLML against the fp64 HIP path on the same data, rtol 1e-3 (sigma_n = 0.1)."""
+    n, d = 33792, 16
+    x, y = orc.synth(n, d, seed=55)
+    hp = np.concatenate([[1.0], np.full(d, 0.5), [0.1]])
+    cov = pg.Compose([pg.Matern52(), pg.White_noise()])
+    m64 = pg.MLE(pg.Exact_GP(T(x), T(y), cov))
+    l64, g64 = m64.loss_and_grad(hp.copy())
+    del m64
+    torch.cuda.empty_cache()
+    l32, g32 = pg.MLE(pg.Exact_GP(T(x).float(), T(y).float(), cov)).loss_and_grad(hp.copy())
+    np.testing.assert_allclose(l32, l64, rtol=1e-3)
+    np.testing.assert_allclose(g32, g64, rtol=5e-2, atol=5e-2 * np.abs(g64).max())
 
 
 def _check_sampler(golden):
