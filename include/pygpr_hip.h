@@ -72,8 +72,10 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
 int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
                          int n, int d, void* dK, void* stream);
 
-/* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag receives the
- * inverses of the 128x128 diagonal blocks ([n/128][128][128]); they drive every later solve. */
+/* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag is the factorisation's
+ * workspace of pg_potrf_worksize(dtype, n) elements: its first n * 128 elements receive the inverses of the 128x128
+ * diagonal blocks ([n/128][128][128]) that drive every later solve (pg_potrs_vec, pg_trtri ... only read that part);
+ * the rest is scratch of the panel step (inverse of the current panel's triangular factor, the panel's solved rows). */
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
 

@@ -16,7 +16,7 @@ PG_KIND_RBF, PG_KIND_MATERN52, PG_KIND_SQDIST = 0, 1, 2
 PG_MAX_COMP, PG_MAX_DIM = 4, 64
 PAD = 256  # every dimension given to the O(n^3) entry points is a multiple of this
 
-GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT, GEMM_NT_64, GEMM_NT_64x128, GEMM_NT_32x64, GEMM_NT_32x128, GEMM_TT_64 = 0, 1, 2, 3, 5, 6, 7, 8, 9, 10
+GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT, GEMM_NT_64, GEMM_NT_64x128, GEMM_NT_32x64, GEMM_NT_32x128, GEMM_TT_64, GEMM_NT_32x32 = 0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11
 
 
 class CovSpec(C.Structure):

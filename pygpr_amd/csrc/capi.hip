@@ -97,7 +97,9 @@ int pg_create(pg_handle* h) {
     {
         const char* e = getenv("PG_NBO");
         c->nbo = e ? atoi(e) : 0;
-        if (c->nbo < 128 || c->nbo % 128) c->nbo = 0;
+        if (c->nbo < 128 || c->nbo % 128 || c->nbo > 2048) c->nbo = 0;
+        const char* v = getenv("PG_PANEL_MODE");
+        c->panel_mode = v ? atoi(v) : 0;
     }
     {   // update stream on all but the last PG_RESERVED_CUS compute units; without it look-ahead stays off
         hipDeviceProp_t prop;
@@ -380,7 +382,7 @@ int pg_set_lookahead(pg_handle h, int on) {
 
 int pg_set_outer_panel(pg_handle h, int columns) {
     NEED(h, "null handle");
-    NEED(columns == 0 || (columns >= 128 && columns % 128 == 0), "outer panel must be 0 (automatic) or a multiple of 128");
+    NEED(columns == 0 || (columns >= 128 && columns % 128 == 0 && columns <= 2048), "outer panel must be 0 (automatic) or a multiple of 128 up to 2048");
     h->nbo = columns;
     return 0;
 }
@@ -410,7 +412,7 @@ int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double
     NEED(h && A && B && C, "null pointer");
     NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
              variant == GEMM_TT_128 || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_NT_32x64 ||
-             variant == GEMM_NT_32x128 || variant == GEMM_TT_64,
+             variant == GEMM_NT_32x128 || variant == GEMM_TT_64 || variant == GEMM_NT_32x32,
          "variant not exposed");
     DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),
              gemm_raw_t<float>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream));

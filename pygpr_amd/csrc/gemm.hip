@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
     typedef Stage<T, BN, TB, BKT> SB;    // B: K-contiguous when transposed
     typedef typename Mfma<T>::acc_t acc_t;
     // wave tile; 4 waves cover BM x BN: 128x128 -> 64x64, 64x256 -> 64x64, 64x64 -> 32x32, 64x128 -> 32x64,
-    // 32x64 -> 16x32, 32x128 -> 32x32
-    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN == 64) ? 16 : 32);
-    constexpr int WTN = (BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64;
+    // 32x64 -> 16x32, 32x128 -> 32x32, 32x32 -> 16x16
+    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN <= 64) ? 16 : 32);
+    constexpr int WTN = (BN == 32) ? 16 : ((BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64);
     constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
     constexpr int WN_ = BN / WTN;                             // waves along N
     static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves must tile the block");
@@ -264,10 +264,11 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
 }
 
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
-    const int BM = (variant == GEMM_NT_32x64 || variant == GEMM_NT_32x128) ? 32
+    const int BM = (variant == GEMM_NT_32x64 || variant == GEMM_NT_32x128 || variant == GEMM_NT_32x32) ? 32
                    : ((variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_TT_64) ? 64 : 128);
     const int BN = (variant == GEMM_NT_RP) ? 256
-                   : ((variant == GEMM_NT_64 || variant == GEMM_NT_32x64 || variant == GEMM_TT_64) ? 64 : 128);
+                   : ((variant == GEMM_NT_64 || variant == GEMM_NT_32x64 || variant == GEMM_TT_64) ? 64
+                      : (variant == GEMM_NT_32x32 ? 32 : 128));
     const int tm = M / BM, tn = N / BN;
     double f = 0;
     for (int ti = 0; ti < tm; ++ti)
@@ -299,8 +300,11 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;
         case GEMM_NT_64x128: rc = launch<T, false, true, 64, 128, 0>(st, p); break;
         case GEMM_NT_32x64: rc = launch<T, false, true, 32, 64, 0, 32>(st, p); break;
-        case GEMM_NT_32x128: rc = launch<T, false, true, 32, 128, 0, 32>(st, p); break;
+        // fp64: a 16-deep K tile keeps the block's LDS at 46 KB (three per CU); with 32 it is 87 KB and one per CU, which
+        // capped the chain's panel solve at a third of its CUs' rate
+        case GEMM_NT_32x128: rc = launch<T, false, true, 32, 128, 0, (sizeof(T) == 8 ? 16 : 32)>(st, p); break;
         case GEMM_TT_64: rc = launch<T, true, true, 64, 64, 0>(st, p); break;
+        case GEMM_NT_32x32: rc = launch<T, false, true, 32, 32, 0, 64>(st, p); break;
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;

@@ -18,6 +18,7 @@
 //     touches; after the loop only Dinv[7] and block row 7 are left.
 // LDS: S[128][130] + 8 x [16][18] diagonal inverses, all in the dynamic region.
 #include "leaf.h"
+#include <cstdlib>
 
 #define NB 128
 #define LD 130
@@ -81,6 +82,47 @@ __device__ __forceinline__ void lds_tile_mm(T* C, int ldc, const T* A, int lda, 
 
 // One 16x16 tile of the inverse, X[p][q] (p > q), by one wave: W = sum_{r=q}^{p-1} L[p][r] X[r][q], X[p][q] = -Dinv[p] W.
 // X[r][q] for r > q is read from upper tile (q, r); the result goes to upper tile (q, p) (also the scratch for W).
+// The two halves are also available on their own: the sum only needs block row p of L and the rows of X above it, so
+// for the last block row it runs before the last diagonal inverse exists.
+template <typename T>
+__device__ __forceinline__ void inv_tile_sum(T* S, const T* Dinv, int p, int q, int lane) {
+    typename Mfma<T>::acc_t acc;
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+    const T* Lp = S + (16 * p + fr) * LD;
+    for (int r = q; r < p; ++r) {
+        T a[4], b[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a[kk] = Lp[16 * r + 4 * kk + fk];
+            b[kk] = (r == q) ? Dinv[q * 16 * DLD + (4 * kk + fk) * DLD + fr] : S[(16 * q + 4 * kk + fk) * LD + 16 * r + fr];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(a[kk], b[kk], acc);
+    }
+    T* Wt = S + (16 * q) * LD + 16 * p;            // tile (q, p): W
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[Mfma<T>::row(lane, r) * LD + fr] = acc[r];
+}
+template <typename T>
+__device__ __forceinline__ void inv_tile_finish(T* S, const T* Dinv, int p, int q, int lane) {
+    typename Mfma<T>::acc_t acc;
+    const int fr = lane & 15, fk = lane >> 4;
+    T* Wt = S + (16 * q) * LD + 16 * p;
+    T a[4], b[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a[kk] = Dinv[p * 16 * DLD + fr * DLD + 4 * kk + fk];
+        b[kk] = Wt[(4 * kk + fk) * LD + fr];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = Mfma<T>::run(a[kk], b[kk], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[Mfma<T>::row(lane, r) * LD + fr] = -acc[r];
+}
 template <typename T>
 __device__ __forceinline__ void inv_tile(T* S, const T* Dinv, int p, int q, int lane) {
     typename Mfma<T>::acc_t acc;
@@ -276,16 +318,176 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
     store_inv_rows(112, 128);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Leaf, second form (default): the diagonal step and the panel solve are ONE register-resident tall-panel step.
+// Waves 0-2 each hold the 16 rows of the diagonal block in lanes 0-15 (redundantly) and 48 rows of the panel below it in
+// lanes 16-63; wave 3 holds the diagonal rows and 16 identity rows.  Per column c: the pivot and the multipliers l_kc come
+// from the diagonal lanes by v_readlane (wave-uniform SGPRs), so the same instructions that factor the diagonal block
+// perform the right-looking solve of the panel rows (and of the identity rows: D^-1) -- no LDS round trip and no barrier
+// between "A" and "B", no branches (a bad pivot is recorded with a compare/select and acted on after the 16 columns).
+// Waves 4-11 meanwhile run the deferred trailing update of the previous micro-panel and the inverse's block row, as before.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
+                                                       int* __restrict__ info, int col0, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* S = reinterpret_cast<T*>(smem_raw);
+    T* Dinv = S + NB * LD;                                  // [8][16][DLD]
+    int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NAB = 4;                                  // waves of the tall-panel step (3 x 48 panel rows + identity rows)
+
+    if (*info != 0) return;
+    if (tid == 0) fail = 0;
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    {   // lower triangle -> LDS, two columns per thread, 64 pairs per row; all loads are issued before the first use
+        constexpr int NLD = (NB * NB / 2 + NTH - 1) / NTH;
+        pair_t v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
+            v[u] = pair_t{(T)0, (T)0};
+            if (idx < NB * NB / 2 && k <= i) v[u] = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
+            if (k + 1 > i) v[u][1] = (T)0;
+            if (idx < NB * NB / 2) *reinterpret_cast<pair_t*>(S + i * LD + k) = v[u];
+        }
+    }
+    __syncthreads();
+
+    const bool want_inv = inv != nullptr && !(ablate & 2);
+    for (int jb = 0; jb < ((ablate & 1) ? 0 : NB / 16); ++jb) {
+        const int c0 = jb * 16, r0 = c0 + 16;
+        if (wave < NAB) {
+            // ---- tall-panel step: lanes 0-15 = diagonal rows, lanes 16-63 = panel rows (waves 0-2) / identity rows (wave 3)
+            const int pl = lane - 16;                                   // panel slot of this lane
+            const int prow = r0 + 48 * wave + pl;                       // its row of S
+            const bool is_diag = lane < 16;
+            const bool is_panel = !is_diag && wave < 3 && prow < NB;
+            const bool is_ident = !is_diag && wave == 3 && pl < 16 && want_inv;
+            const T* src = S + (is_diag ? c0 + lane : (is_panel ? prow : c0)) * LD + c0;
+            T row[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T v = src[c];
+                row[c] = (is_diag || is_panel) ? v : ((is_ident && c == pl) ? (T)1 : (T)0);
+            }
+            int first_bad = 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T piv = bcast_lane(row[c], c);                    // wave-uniform
+                first_bad = (piv > (T)0) ? first_bad : min(first_bad, c);
+                const T rs = inv_sqrt(piv);
+                const T lrc = row[c] * rs;
+                row[c] = lrc;
+#pragma unroll
+                for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
+            }
+            if (first_bad < 16) {                                        // wave-uniform (piv is)
+                if (wave == 0 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
+            } else if (is_diag) {
+                if (wave == 0) {
+                    T* D = S + (c0 + lane) * LD + c0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) D[c] = (c <= lane) ? row[c] : (T)0;
+                }
+            } else if (is_panel) {
+                T* P = S + prow * LD + c0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) P[c] = row[c];
+            } else if (is_ident) {
+                T* dst = Dinv + jb * 16 * DLD + pl;                      // column pl of D^-1
+#pragma unroll
+                for (int c = 0; c < 16; ++c) dst[c * DLD] = row[c];
+            }
+        } else if (jb > 0) {
+            // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti; then block row
+            // jb - 1 of the inverse (its diagonal inverse was formed by wave 3 in the previous step)
+            const int pc0 = c0 - 16, pr0 = c0;
+            const int pnt = (NB - pr0) / 16;
+            const int nrest = pnt * (pnt - 1) / 2;
+            const int nx = want_inv ? jb - 1 : 0;
+            // last step: the wave that finishes X[6][q] goes on to the sum of X[7][q] (rows 0-6 of X and block row 7 of L
+            // are final; only the last diagonal inverse, formed by wave 3 right now, is missing)
+            const bool last = want_inv && jb == NB / 16 - 1;
+            for (int t = wave - NAB; t < nrest + nx + (last ? 1 : 0); t += NWV - NAB) {
+                if (last && t == nrest + nx) {
+                    inv_tile_sum<T>(S, Dinv, jb, jb - 1, lane);          // q = 6: L[7][6] Dinv[6]
+                    continue;
+                }
+                if (t < nrest) {
+                    int u = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                    while (u * (u + 1) / 2 > t) --u;
+                    while ((u + 1) * (u + 2) / 2 <= t) ++u;
+                    const int ti = u + 1, tj = t - u * (u + 1) / 2 + 1;
+                    lds_tile_mm<T, true>(S + (pr0 + ti * 16) * LD + pr0 + tj * 16, LD, S + (pr0 + ti * 16) * LD + pc0, LD,
+                                         S + (pr0 + tj * 16) * LD + pc0, LD, 16, (T)-1, (T)1, lane);
+                } else {
+                    inv_tile<T>(S, Dinv, jb - 1, t - nrest, lane);
+                    if (last) inv_tile_sum<T>(S, Dinv, jb, t - nrest, lane);
+                }
+            }
+        }
+        __syncthreads();
+        if (fail) return;
+        if (r0 >= NB) break;
+        const int nt = (NB - r0) / 16;
+        // ---- first tile column of the trailing update: next diagonal block and next panel, T <- T - P P^T
+        for (int t = wave; t < nt; t += NWV)
+            lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + r0, LD, S + (r0 + t * 16) * LD + c0, LD, S + r0 * LD + c0, LD, 16,
+                                 (T)-1, (T)1, lane);
+        __syncthreads();
+    }
+
+    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+        if (k > i) v[0] = (T)0;
+        if (k + 1 > i) v[1] = (T)0;
+        *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+    }
+    if (!want_inv) return;
+    auto store_inv_rows = [&](int row_lo, int row_hi) {
+        for (int idx = row_lo * 64 + tid; idx < row_hi * 64; idx += NTH) {
+            const int i = idx >> 6, k = (idx & 63) * 2;
+            const int pb = i >> 4, qb = k >> 4, ii = i & 15;
+            pair_t v = {(T)0, (T)0};
+            if (qb == pb) {
+                const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
+                v[0] = (k <= i) ? Dv[0] : (T)0;
+                v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
+            } else if (qb < pb) {
+                const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
+                v[0] = Xt[0];
+                v[1] = Xt[1];
+            }
+            *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+        }
+    };
+    store_inv_rows(0, 112);
+    if (ablate & 1) return;
+    for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);   // sums and Dinv[7] are in place (last step)
+    __syncthreads();
+    store_inv_rows(112, 128);
+}
+
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
-    auto kern = pg_leaf_kernel<T>;
+    static const int form = getenv("PG_LEAF") ? atoi(getenv("PG_LEAF")) : 2;   // 1: round-1 leaf (A / B / C phases), 2: fused tall-panel step
     if (!attr_done) {
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
+    if (form == 1) hipLaunchKernelGGL(pg_leaf_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
+    else hipLaunchKernelGGL(pg_leaf2_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
     PG_CHECK(hipGetLastError());
     return 0;
 }

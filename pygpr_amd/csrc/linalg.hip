@@ -15,6 +15,7 @@
 #include "linalg.h"
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #define NB 128      // diagonal block / leaf size; inv_diag holds [n/128][128][128]
 // Outer panel of the Cholesky.  Narrow panels keep the serial chain short (its U products grow with the panel), wide
@@ -37,6 +38,21 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const T* __restrict__ 
     T* d = dst + (long)b * NB * ldd + (long)b * NB;
     for (int idx = blockIdx.y * 256 + threadIdx.x; idx < NB * NB; idx += gridDim.y * 256)
         d[(long)(idx >> 7) * ldd + (idx & 127)] = s[idx];
+}
+
+// dst[r][0:cols] <- src[r][0:cols] for r < rows (16-byte vectors; cols a multiple of 128): the panel's solved rows going home
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, long lds_, T* __restrict__ dst, long ldd,
+                                                        int rows, int cols) {
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int vpr = cols / VE;                       // vectors per row
+    const long total = (long)rows * vpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / vpr;
+        const int c = (int)(idx % vpr) * VE;
+        *reinterpret_cast<vec_t*>(dst + r * ldd + c) = *reinterpret_cast<const vec_t*>(src + r * lds_ + c);
+    }
 }
 
 template <typename T> __global__ __launch_bounds__(256) void tril_kernel(T* __restrict__ A, long lda, int n) {
@@ -346,11 +362,17 @@ template <typename T> static GemmP<T> gp0() {
     return p;
 }
 
-long pg_potrf_worksize_impl(int n) { return (long)n * NB; }
+// inv_diag [n/128][128][128], then the work area of the panel step: W = inverse of the current outer panel's triangular
+// factor (at most 2048 x 2048) and Xs = the panel's solved rows before they are copied back (n x at most 2048).
+#define NBO_MAX 2048
+long pg_potrf_worksize_impl(int n) {
+    const long w = std::min<long>(n, NBO_MAX);
+    return (long)n * NB + w * w + (long)n * w;
+}
 
 template <typename T>
 int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax) {
-    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    if (n <= 0 || n % NB) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, NB); return -2; }
     hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 8), dim3(256), 0, st, invD, M, ldm);
     LAUNCH_CHECK();
     // invariant: the diagonal is tiled by `nfull` inverted blocks of size h plus one smaller inverted block `rem`
@@ -440,7 +462,15 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
     const int NBO = pg_nbo(ctx, n);
-    const int npan = (n + NBO - 1) / NBO;
+    // Outer panel boundaries (uniform; the last one may be short).  Measured on the round-2 build and left out: cutting the
+    // first panel in two (256 + NBO - 256 columns) so that the first big update starts after two leaves instead of eight,
+    // and half-width panels over the last 4096 / 8192 columns -- both within +-0.2 ms at n = 12288 / 16384: the schedule
+    // is throughput-bound on the whole (the chain and the updates share the chip at 62-77 % MFMA use per CU), so shifting
+    // work between its two streams does not shorten it.
+    std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
+    for (int c = 0; c < n; c += NBO) pb.push_back(c);
+    pb.push_back(n);
+    const int npan = (int)pb.size() - 1;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
     hipStream_t ps = la ? ctx->aux : st;   // panel stream
     hipStream_t us = la ? ctx->upd : st;   // update stream
@@ -455,28 +485,58 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // fused L^-1: split the diagonal at `split` columns; the leading part is inverted in the background once its
     // columns are final (after the chain of panel split/NBO - 1), together with the first top-level product
     // (below n = 5120 the cross-stream split costs more than the overlap returns: 3.66 vs 3.79 ms at n = 4096)
-    const int split = (Minv && la && ctx->bg && npan >= 4 && n >= 5120) ? (npan / 2) * NBO : 0;
+    const int split = (Minv && la && ctx->bg && n / NBO >= 4 && n >= 5120) ? ((n + NBO - 1) / NBO / 2) * NBO : 0;
+    const long NBW = std::min<long>(n, NBO_MAX);
+    T* Wt = invD + (long)n * NB;          // inverse of the current panel's triangular factor, leading dimension = panel width
+    T* Xs = Wt + NBW * NBW;               // the panel's solved rows (out of place), leading dimension = panel width
     for (int o = 0; o < npan; ++o) {
-        const int o0 = o * NBO, oend = std::min(n, o0 + NBO);
-        for (int k0 = o0; k0 < oend; k0 += NB) {   // Chain(o)
+        const int o0 = pb[o], oend = pb[o + 1];
+        // Chain(o): left-looking 128-column steps (U, leaf, T).
+        // panel modes (ctx->panel_mode, PG_PANEL_MODE): 0 (default) = every 128-column step works on all rows below;
+        // 1 = recursive panel: the steps only touch the panel's own triangle, then its factor is inverted (recursive
+        // doubling) and ALL rows below are solved as one full-tile product X = A[oend:n, panel] inv(L_panel)^T.  Measured
+        // slower with one launch per step (n = 16384: 34.4 vs 32.7 ms, n = 8192: 8.2 vs 7.2): the triangle's short launches
+        // and the six of the inverse cost more latency than the skinny products lose.  Kept behind the switch.
+        // (A split chain -- the rows below the panel on a further stream behind one event per step -- was measured and
+        // removed: a fifth stream in the process costs the look-ahead 20 % whether it is used or not.)
+        const int mode = (oend < n) ? ctx->panel_mode : 0;
+        const bool v2 = mode == 1;
+        const int tri_end = v2 ? oend : n;     // last row the panel stream's 128-column steps touch
+        for (int k0 = o0; k0 < oend; k0 += NB) {
             T* Akk = A + (long)k0 * lda + k0;
             T* inv = invD + (long)(k0 / NB) * NB * NB;
             if (k0 > o0) {   // U: bring this column block up to date with the panel's earlier columns
                 GemmP<T> p = gp0<T>(); p.info = info;
-                p.M = n - k0; p.N = NB; p.K = k0 - o0;
+                p.M = tri_end - k0; p.N = NB; p.K = k0 - o0;
                 p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
                 p.alpha = (T)-1; p.beta = (T)1;
-                // fewer than two 64-row workgroups per CU: half the row tile keeps two waves on every SIMD (gemm.h)
-                if ((rc = pg_gemm<T>(ctx, ps, p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64, p))) return rc;
+                // fewer than two 64-row workgroups per CU: half the row tile keeps two waves on every SIMD (gemm.h); in the
+                // chain-bound tail the launch's latency is what counts: 32 x 32 tiles with a 64-deep K tile
+                static const int u32rows = getenv("PG_U32_ROWS") ? atoi(getenv("PG_U32_ROWS")) : 8192;
+                const int uv = (p.M <= u32rows && p.K % 64 == 0) ? GEMM_NT_32x32 : (p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64);
+                if ((rc = pg_gemm<T>(ctx, ps, uv, p))) return rc;
             }
             if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
-            const int m = n - k0 - NB;
+            const int m = tri_end - k0 - NB;
             if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
                 GemmP<T> p = gp0<T>(); p.info = info;
                 p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
                 p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
                 if ((rc = pg_gemm<T>(ctx, ps, m <= 12288 ? GEMM_NT_32x128 : GEMM_NT_64x128, p))) return rc;
             }
+        }
+        if (v2) {
+            const int pw = oend - o0, mb = n - oend;
+            if ((rc = pg_trtri_t<T>(ctx, ps, pw, A + (long)o0 * lda + o0, lda, invD + (long)(o0 / NB) * NB * NB, Wt, (long)pw))) return rc;
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = mb; p.N = pw; p.K = pw; p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = Wt; p.ldb = pw; p.C = Xs; p.ldc = pw;
+            p.khi = 2;       // W is lower triangular (and what lies above its diagonal 128-blocks is scratch of the doubling)
+            const long tiles = (long)(mb / 128) * (pw / 128);
+            if ((rc = pg_gemm<T>(ctx, ps, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            const long vecs = (long)mb * pw / (16 / sizeof(T));
+            hipLaunchKernelGGL(copy_rows_kernel<T>, dim3((unsigned)std::min<long>((vecs + 255) / 256, 4096)), dim3(256), 0, ps, Xs, (long)pw,
+                               A + (long)oend * lda + o0, lda, mb, pw);
+            LAUNCH_CHECK();
         }
         if (oend >= n) break;
         if (la) {
@@ -489,7 +549,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 if ((rc = trtri_top<T>(ctx, ctx->bg, split, n - split, A, lda, Minv, ldm, true, false))) return rc;
             }
         }
-        const int o2 = std::min(n, oend + NBO);   // first column right of panel o+1
+        const int o2 = (o + 2 <= npan) ? pb[o + 2] : n;   // first column right of panel o+1
         {   // Sa(o): panel o+1's columns -= panel o
             GemmP<T> p = gp0<T>(); p.info = info;
             p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;

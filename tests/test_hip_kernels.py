@@ -100,6 +100,12 @@ def test_gemm_skinny_chain_variants(ops):
     cf = dev(c0[:416], torch.float32)
     ops.gemm_raw(GEMM_NT_32x64, 416, 128, k, -1.0, dev(a, torch.float32), dev(b, torch.float32), 1.0, cf)
     np.testing.assert_allclose(host(cf), c0 - a @ b.T, atol=2e-3)
+    # the tail's U product: 32 x 32 tiles, 64-deep K tile
+    from pygpr_amd._lib import GEMM_NT_32x32
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-3)):
+        c = dev(c0, dt)
+        ops.gemm_raw(GEMM_NT_32x32, 416, 128, k, -1.0, dev(a, dt), dev(b, dt), 1.0, c)
+        np.testing.assert_allclose(host(c), c0 - a @ b.T, atol=tol)
 
 
 def test_gemm_triangular_k_ranges(ops):
