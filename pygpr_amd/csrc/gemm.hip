@@ -16,9 +16,10 @@
 
 #define BK 16
 
-template <typename T, int R, bool KCONT, int BKT = BK> struct Stage {
+template <typename T, int R, bool KCONT, int BKT = BK, int NTH = 256> struct Stage {
     static constexpr int VE = 16 / sizeof(T);
-    static constexpr int NV = (R * BKT / VE) / 256;
+    static constexpr int NV = (R * BKT / VE) / NTH;
+    static_assert(NV >= 1, "fewer 16-byte vectors in the stage than threads");
     static constexpr int LDS_ELEMS = KCONT ? R * (BKT + 2) : BKT * (R + 16);
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     typedef T half_t __attribute__((ext_vector_type(VE / 2)));
@@ -27,7 +28,7 @@ template <typename T, int R, bool KCONT, int BKT = BK> struct Stage {
     __device__ __forceinline__ void load(const T* __restrict__ g, long ld, int r0, int k0, int tid) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int idx = tid + 256 * q;
+            const int idx = tid + NTH * q;
             const T* p;
             if (KCONT) {
                 const int row = idx / (BKT / VE), kv = idx % (BKT / VE);
@@ -42,7 +43,7 @@ template <typename T, int R, bool KCONT, int BKT = BK> struct Stage {
     __device__ __forceinline__ void store(T* s, int tid) const {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int idx = tid + 256 * q;
+            const int idx = tid + NTH * q;
             if (KCONT) {
                 const int row = idx / (BKT / VE), kv = idx % (BKT / VE);
                 T* d = s + row * (BKT + 2) + kv * VE;   // 8-byte aligned for fp32, 16 for fp64
@@ -67,18 +68,20 @@ template <typename T, int R, bool KCONT, int BKT = BK> struct Stage {
     }
 };
 
-template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK>
-__global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
-    typedef Stage<T, BM, !TA, BKT> SA;   // A: K-contiguous when not transposed
-    typedef Stage<T, BN, TB, BKT> SB;    // B: K-contiguous when transposed
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP<T> p) {
+    constexpr int NTH = 64 * NW;
+    typedef Stage<T, BM, !TA, BKT, NTH> SA;   // A: K-contiguous when not transposed
+    typedef Stage<T, BN, TB, BKT, NTH> SB;    // B: K-contiguous when transposed
     typedef typename Mfma<T>::acc_t acc_t;
     // wave tile; 4 waves cover BM x BN: 128x128 -> 64x64, 64x256 -> 64x64, 64x64 -> 32x32, 64x128 -> 32x64,
     // 32x64 -> 16x32, 32x128 -> 32x32, 32x32 -> 16x16
+    // (NW == 8: eight waves of 64 x 32 on the 128 x 128 block -- half the accumulators per wave, twice the waves per SIMD)
     constexpr int WTM = (BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN <= 64) ? 16 : 32);
-    constexpr int WTN = (BN == 32) ? 16 : ((BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64);
+    constexpr int WTN = (NW == 8) ? 32 : ((BN == 32) ? 16 : ((BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64));
     constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
     constexpr int WN_ = BN / WTN;                             // waves along N
-    static_assert((BM / WTM) * (BN / WTN) == 4, "4 waves must tile the block");
+    static_assert((BM / WTM) * (BN / WTN) == NW, "the waves must tile the block");
 
     if (p.info && *p.info != 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
                 }
     } else {
         // column sums of squares of this wave's 64 rows -> part[(m0/64 + wm)][col]
-        static_assert(EPI == 0 || (WTM == 64 && WTN == 64), "the column-sum epilogue assumes 64 x 64 wave tiles");
+        static_assert(EPI == 0 || WTM == 64, "the column-sum epilogue assumes 64-row wave tiles");
 #pragma unroll
         for (int j = 0; j < MIN; ++j) {
             T s = (T)0;
@@ -231,20 +234,20 @@ __global__ __launch_bounds__(256, 2) void pg_gemm_kernel(GemmP<T> p) {
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             if (lane < 16) {
-                const int col = n0 + wn * 64 + j * 16 + lane;
+                const int col = n0 + wn * WTN + j * 16 + lane;
                 p.part[(long)(m0 / 64 + wm) * p.ldp + col + zb * p.sC] = s;
             }
         }
     }
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK>
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
 static int launch(hipStream_t st, const GemmP<T>& p) {
-    typedef Stage<T, BM, !TA, BKT> SA;
-    typedef Stage<T, BN, TB, BKT> SB;
+    typedef Stage<T, BM, !TA, BKT, 64 * NW> SA;
+    typedef Stage<T, BN, TB, BKT, 64 * NW> SB;
     const size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T);
     static bool attr_done = false;
-    auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI, BKT>;
+    auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI, BKT, NW>;
     if (!attr_done) {
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -258,7 +261,7 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
     const long tiles = p.tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
     if (tiles == 0 || p.batch == 0) return 0;
     dim3 grid((unsigned)tiles, (unsigned)p.batch, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
     PG_CHECK(hipGetLastError());
     return 0;
 }
@@ -285,18 +288,25 @@ double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi
 
 template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p_in) {
     static const int noxcd = getenv("PG_NOXCD") ? atoi(getenv("PG_NOXCD")) : 0;
+    // 128 x 128 blocks: eight waves of 64 x 32 (default) or the round-1 form, four waves of 64 x 64 (PG_GEMM_W4=1).  Same
+    // numbers bit for bit; four waves per SIMD instead of two cover the staging and barrier stalls: uniform 8192^3 69.1 ->
+    // 71.8 TFLOP/s, K = 1024 SYRK 60.1 -> 64.0, L^-T L^-1 64.9 -> 67.5 (16 waves of 32 x 32 are slower: 59-67).
+    // fp32 keeps four waves (its 64 x 64 wave tile needs half the registers: already four waves per SIMD; eight were 3 % slower).
+    static const int w4env = getenv("PG_GEMM_W4") ? atoi(getenv("PG_GEMM_W4")) : 0;
+    static const int ss4 = getenv("PG_SS_W4") ? atoi(getenv("PG_SS_W4")) : 1;   // the column-sum epilogue: four waves (8.63 vs 8.85 ms, config-2 predict)
+    const bool w4 = w4env || sizeof(T) == 4 || (variant == GEMM_NN_128_SS && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;
     switch (variant) {
-        case GEMM_NT_128: rc = launch<T, false, true, 128, 128, 0>(st, p); break;
+        case GEMM_NT_128: rc = w4 ? launch<T, false, true, 128, 128, 0>(st, p) : launch<T, false, true, 128, 128, 0, BK, 8>(st, p); break;
         case GEMM_NT_RP: rc = launch<T, false, true, 64, 256, 0>(st, p); break;
-        case GEMM_NN_128: rc = launch<T, false, false, 128, 128, 0>(st, p); break;
-        case GEMM_TN_128: rc = launch<T, true, false, 128, 128, 0>(st, p); break;
-        case GEMM_NN_128_SS: rc = launch<T, false, false, 128, 128, 1>(st, p); break;
-        case GEMM_TT_128: rc = launch<T, true, true, 128, 128, 0>(st, p); break;
+        case GEMM_NN_128: rc = w4 ? launch<T, false, false, 128, 128, 0>(st, p) : launch<T, false, false, 128, 128, 0, BK, 8>(st, p); break;
+        case GEMM_TN_128: rc = w4 ? launch<T, true, false, 128, 128, 0>(st, p) : launch<T, true, false, 128, 128, 0, BK, 8>(st, p); break;
+        case GEMM_NN_128_SS: rc = w4 ? launch<T, false, false, 128, 128, 1>(st, p) : launch<T, false, false, 128, 128, 1, BK, 8>(st, p); break;
+        case GEMM_TT_128: rc = w4 ? launch<T, true, true, 128, 128, 0>(st, p) : launch<T, true, true, 128, 128, 0, BK, 8>(st, p); break;
         case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;
         case GEMM_NT_64x128: rc = launch<T, false, true, 64, 128, 0>(st, p); break;
         case GEMM_NT_32x64: rc = launch<T, false, true, 32, 64, 0, 32>(st, p); break;

@@ -1,7 +1,9 @@
 """Sum FETCH_SIZE / WRITE_SIZE (KiB per dispatch) over the kernels of the LAST evaluation in two rocprofv3 --pmc
 output directories (see probe_eval_once.py).  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads -> doubled."""
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygpr_amd import _lib
 def load(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
@@ -21,5 +23,5 @@ for d, c in ((sys.argv[1], "FETCH_SIZE"), (sys.argv[2], "WRITE_SIZE")):
 for g in out.values():
     g["hbm_bytes"] = (2.0 * g["FETCH_SIZE_KiB"] + g["WRITE_SIZE_KiB"]) * 1024.0
     g["hbm_bytes_per_launch"] = g["hbm_bytes"] / max(1, g["launches"])
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/probe_eval_once.py; "
+print(json.dumps({"build": _lib.build_id(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/probe_eval_once.py; "
                             "one NLML+grad evaluation at N=16384; FETCH_SIZE doubled (gfx950 correction)", "kernels": out}, indent=1))

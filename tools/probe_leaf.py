@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops
 ops = get_ops()
 rng = np.random.default_rng(0)

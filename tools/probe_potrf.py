@@ -1,7 +1,7 @@
 """potrf / trtri / lauum only, for rocprofv3 --kernel-trace --stats."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops, make_spec
 ops = get_ops()
 n, d = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 8

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops, make_spec
 ops = get_ops()
 for n in ([int(a) for a in sys.argv[1:]] or [8192, 16384]):
