@@ -27,7 +27,7 @@ template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_t
 // Taylor polynomial to degree 13 on |r| <= ln2/2 (truncation 4e-18 relative); <= 2 ulp, subnormal results via
 // v_ldexp_f64.  Arguments are <= 0 here; anything below -800 gives 0.
 __device__ __forceinline__ double pg_exp(double x) {
-    x = fmax(x, -800.0);
+    x = (x < -800.0) ? -800.0 : x;      // not fmax: a NaN argument (NaN coordinate or hyper-parameter) must stay NaN
     const double kf = __builtin_rint(x * 1.44269504088896338700e+00);
     double r = __builtin_fma(-kf, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-kf, 1.90821492927058770002e-10, r);

@@ -561,6 +561,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
                 PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
             }
+            // (64 x 64 below 1024 large tiles; re-swept with the eight-wave 128 x 128 blocks: 256 is 0.4-0.8 ms slower at 16384)
             if ((rc = pg_gemm<T>(ctx, la ? ps : us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         const int m2 = n - o2;
@@ -572,6 +573,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
             const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
             // (threshold swept 512 / 1024 / 2048: 2048 is 2 % faster at n = 8192 and neutral at 16384)
+            // (re-swept with the eight-wave blocks, 2048 / 1024 / 512 / 256: 2048 stays best at 8192, neutral at 16384)
             if ((rc = pg_gemm<T>(ctx, us, tiles < 2048 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         if (la) {

@@ -24,9 +24,13 @@ from .loss import MLE, Loss
 
 
 def _dist_on(flag):
+    """Collectives are used when asked for and the process group has more than one rank (PG_DIST_SINGLE_RANK=1: also with
+    one -- lets a one-GPU box run the RCCL code path end to end)."""
     if flag is None:
         return False
-    return bool(flag) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    import os
+    min_world = 1 if os.environ.get("PG_DIST_SINGLE_RANK") else 2
+    return bool(flag) and dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world
 
 
 def expert_block(nc, rank, world):

@@ -273,6 +273,25 @@ def test_sqdist_kind_and_centres_any_d(ops):
         assert np.array_equal(idx.cpu().numpy(), np.argmin(d2, axis=1))
 
 
+def test_kernel_build_propagates_nan(ops):
+    """A NaN coordinate must reach K as NaN (torch's exp does; the reference's Cholesky then raises): the device exp must
+    not launder it into a finite value."""
+    rng = np.random.default_rng(4)
+    n, d = 70, 3
+    x = rng.random((n, d))
+    x[23, 1] = np.nan
+    hp = np.array([1.0, 0.7, 0.8, 0.9, 0.1])
+    for dt in (torch.float64, torch.float32):
+        k = ops.empty(256, 256, dtype=dt)
+        ops.kernel_build(_spec([orc.SE, orc.WN], d), dev(hp), dev(x, dt), None, k, jitter=1e-7)
+        got = host(k)
+        assert np.isnan(got[23, :n]).all() and np.isnan(got[:n, 23]).all()
+        assert np.isfinite(np.delete(np.delete(got[:n, :n], 23, 0), 23, 1)).all()
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.potrf(k, ops.potrf_workspace(256, dt), info)
+        assert int(info.item()) == 24            # LAPACK convention: the leading minor of order 24
+
+
 def test_kernel_build_fp32(ops):
     from pygpr_amd._ops import pad_to
 

@@ -548,3 +548,57 @@ def test_samplers_and_partition(golden):
     d2 = ((x[:, None, :] - c[None, :, :]) ** 2).sum(2)
     assert np.array_equal(N(nearest_centre(T(x), T(c))), np.argmin(d2, axis=1))
     np.testing.assert_allclose(N(pg.euclidean_dist(T(x), T(c))), d2, atol=1e-13)
+
+
+_NCCL_SCRIPT = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", PG_DIST_SINGLE_RANK="1",
+                  HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import pygpr_amd as pg
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "grbcm.npz"))
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+p = "g1_"
+cov = pg.Compose([pg.Squared_exponential(), pg.White_noise()])
+m = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), cov, distributed=True)
+assert m.distributed and dist.get_backend() == "nccl"
+m.gpg.set_params(T(g[p + "hpg"])); m.set_local_params(T(g[p + "hpl"]))
+mu, var = m.predict(T(g[p + "xs"]), var="diag")
+np.testing.assert_allclose(mu.numpy(), g[p + "mu"], atol=1e-10)
+np.testing.assert_allclose(var.numpy(), g[p + "var"], atol=1e-11)
+m.set_params(T(g[p + "hpg"]))
+mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
+np.testing.assert_allclose(cov_f.numpy(), g[p + "cov_full"], rtol=1e-6, atol=1e-10)
+loss, grad = pg.GRBCM_MLE(m).loss_and_grad(g[p + "hpg"].copy())
+ref = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), cov)
+ref.set_params(T(g[p + "hpg"]))
+l2, g2 = pg.GRBCM_MLE(ref).loss_and_grad(g[p + "hpg"].copy())
+assert float(loss) == float(l2) and np.array_equal(grad, g2)
+xl = g[p + "xl"].copy(); xl[-1, 3, 0] = np.nan
+bad = pg.GRBCM(T(xl), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), cov, distributed=True)
+bad.set_params(T(g[p + "hpg"]))
+for call in (lambda: bad.predict(T(g[p + "xs"]), var="diag"), lambda: pg.GRBCM_MLE(bad).loss_and_grad(g[p + "hpg"].copy())):
+    try:
+        call(); raise SystemExit("did not raise")
+    except torch.linalg.LinAlgError:
+        pass
+dist.barrier(); dist.destroy_process_group()
+print("NCCL-OK")
+"""
+
+
+def test_rccl_code_path_single_rank(tmp_path):
+    """The `nccl` (= RCCL) branches of GRBCM / GRBCM_MLE -- device-side all-reduces of the [3, m] + status buffer, the
+    [m_pad, m_pad] weighted precision, the [1 + nhp] + status vector, the status relay of a non-PD expert -- run end to end
+    on this one-GPU box over a one-rank RCCL communicator (a fresh process: the process group is global state)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text(_NCCL_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root, str(29500 + os.getpid() % 2000)], capture_output=True, text=True,
+                       timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and "NCCL-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
