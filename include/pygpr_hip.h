@@ -118,6 +118,14 @@ int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans
 int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const void* y, const void* alpha,
                   double* out, void* stream);
 
+/* The same alpha and NLML as pg_trmv x 2 + pg_nlml_value (alpha = Minv^T (Minv y), loss.py:102-109), arranged to overlap with the
+ * caller's next launch: the log-determinant is read from L on `stream` (K^-1 may overwrite L next), then the two HBM-bound
+ * triangular mat-vecs and the value run on the handle's side stream beside the MFMA-bound pg_lauum the caller enqueues next.
+ * out[0] receives the NLML (out[1] is scratch: log det K); u, alpha: n elements; work: (n/256) n elements.  Any later entry point
+ * on `stream` other than pg_lauum waits for this work before it starts, so the caller needs no extra synchronisation. */
+int pg_alpha_nlml_async(pg_handle h, int dtype, int n_real, int n, const void* L, long ldl, const void* Minv, long ldm, const void* y,
+                        void* u, void* alpha, void* work, double* out, void* stream);
+
 /* grad[k] = 1/2 sum (Kinv - alpha alpha^T) o dK/dtheta_k  == -1/2 (tr1 - tr2) of loss.py:116-121 */
 long pg_nlml_grad_worksize(int n, int nhp); /* doubles */
 int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n,

@@ -47,6 +47,7 @@ _SIGS = {
     "pg_potri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
     "pg_logdet": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp]),
     "pg_trmv": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp]),
+    "pg_alpha_nlml_async": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_nlml_value": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
     "pg_nlml_grad_worksize": (_l, [_i, _i]),
     "pg_nlml_grad": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),

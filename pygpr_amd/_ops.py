@@ -170,6 +170,14 @@ class HipOps:
         _lib.check(self.lib.pg_nlml_value(self.h, _code(chol.dtype), n, _p(chol), chol.stride(0), _p(y), _p(alpha),
                                           _p(out), self._st()), "pg_nlml_value")
 
+    def alpha_nlml_async(self, chol, minv, y, u, alpha, work, n, out):
+        """alpha = minv^T (minv y) and out[0] = NLML (out[1]: log det, scratch), overlapped with the next pg_lauum."""
+        self._chk(chol, minv, y, u, alpha, work, out)
+        assert out.dtype == torch.float64 and out.numel() >= 2
+        _lib.check(self.lib.pg_alpha_nlml_async(self.h, _code(chol.dtype), int(n), chol.shape[0], _p(chol), chol.stride(0), _p(minv),
+                                                minv.stride(0), _p(y), _p(u), _p(alpha), _p(work), _p(out), self._st()),
+                   "pg_alpha_nlml_async")
+
     def nlml_grad_worksize(self, n, nhp):
         return self.lib.pg_nlml_grad_worksize(n, nhp)
 

@@ -62,6 +62,21 @@ void pg_set_error(const char* fmt, ...) {
         return -1;                                                           \
     } while (0)
 
+// pg_alpha_nlml_async leaves work on the handle's side stream; every entry point that may read its outputs (everything that
+// takes a stream except pg_lauum, which is meant to overlap with it) first makes its stream wait for that work.
+static int join_side(pg_ctx* h, void* stream) {
+    if (h && h->side_pending) {
+        PG_CHECK(hipStreamWaitEvent(ST(stream), h->ev[5], 0));
+        h->side_pending = 0;
+    }
+    return 0;
+}
+#define JOIN(h, stream)                         \
+    do {                                        \
+        int _j = join_side((h), (stream));      \
+        if (_j) return _j;                      \
+    } while (0)
+
 template <typename T>
 static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alpha, const void* A, long lda, const void* B,
                       long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream) {
@@ -172,6 +187,7 @@ static int check_spec(const pg_covspec* s, const char* fn, bool allow_sqdist = f
 int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* Xr, long ldr, int nr,
                     const void* Xc, long ldc, int nc, int d, int lower_only, int accumulate, double jitter, void* K,
                     long ldk, int rows_pad, int cols_pad, void* stream) {
+    JOIN(h, stream);
     NEED(h && hp && Xr && K, "null pointer");
     if (check_spec(spec, __func__, true)) return -1;
     const int sym = (Xc == nullptr);
@@ -188,6 +204,7 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
 
 int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
                          int n, int d, void* dK, void* stream) {
+    JOIN(h, stream);
     NEED(h && hp && X && dK, "null pointer");
     if (check_spec(spec, __func__)) return -1;
     DISPATCH(dtype, pg_kgrad<double>(ST(stream), *spec, hp, (const double*)X, ldx, n, d, (double*)dK),
@@ -197,6 +214,7 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
 long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize_impl(n); }
 
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
+    JOIN(h, stream);
     NEED(h && A && inv_diag && info, "null pointer");
     NEED(lda >= n, "lda < n");
     DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, nullptr, 0),
@@ -205,6 +223,7 @@ int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, i
 
 int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
                    void* stream) {
+    JOIN(h, stream);
     NEED(h && A && inv_diag && info && Minv, "null pointer");
     NEED(lda >= n && ldm >= n && A != Minv, "bad leading dimension / aliasing");
     DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, (double*)Minv, ldm),
@@ -215,6 +234,7 @@ long pg_potrs_vec_worksize(int dtype, int n) { (void)dtype; return pg_potrs_vec_
 
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
                  void* work, void* stream) {
+    JOIN(h, stream);
     NEED(h && L && inv_diag && y && x && work, "null pointer");
     DISPATCH(dtype,
              pg_potrs_vec_t<double>(h, ST(stream), n, (const double*)L, ldl, (const double*)inv_diag, (const double*)y,
@@ -225,6 +245,7 @@ int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const v
 
 int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Minv, long ldm,
              void* stream) {
+    JOIN(h, stream);
     NEED(h && L && inv_diag && Minv, "null pointer");
     NEED(L != Minv, "pg_trtri is out of place");
     DISPATCH(dtype,
@@ -241,6 +262,7 @@ int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Ki
 
 int pg_potri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Kinv, long ldk, void* work,
              void* stream) {
+    JOIN(h, stream);
     NEED(h && L && inv_diag && Kinv && work, "null pointer");
     NEED(work != L && work != Kinv, "pg_potri: work must not alias L or Kinv");
     NEED(ldl >= n && ldk >= n, "leading dimension < n");
@@ -250,6 +272,7 @@ int pg_potri(pg_handle h, int dtype, int n, const void* L, long ldl, const void*
 }
 
 int pg_logdet(pg_handle h, int dtype, int n, const void* L, long ldl, double* out, void* stream) {
+    JOIN(h, stream);
     NEED(h && L && out, "null pointer");
     NEED(n > 0 && ldl >= n, "bad size");
     DISPATCH(dtype, pg_logdet_t<double>(ST(stream), n, (const double*)L, ldl, out),
@@ -258,6 +281,7 @@ int pg_logdet(pg_handle h, int dtype, int n, const void* L, long ldl, double* ou
 
 int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y, void* work,
             void* stream) {
+    JOIN(h, stream);
     NEED(h && Minv && x && y, "null pointer");
     NEED(!trans || work, "transposed product needs a workspace");
     NEED(x != y, "pg_trmv is out of place");
@@ -266,8 +290,21 @@ int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans
              pg_trmv_t<float>(h, ST(stream), n, (const float*)Minv, ldm, trans, (const float*)x, (float*)y, (float*)work));
 }
 
+int pg_alpha_nlml_async(pg_handle h, int dtype, int n_real, int n, const void* L, long ldl, const void* Minv, long ldm, const void* y,
+                        void* u, void* alpha, void* work, double* out, void* stream) {
+    JOIN(h, stream);
+    NEED(h && L && Minv && y && u && alpha && work && out, "null pointer");
+    NEED(n_real > 0 && n_real <= n && ldl >= n && ldm >= n, "bad size");
+    DISPATCH(dtype,
+             pg_alpha_nlml_async_t<double>(h, ST(stream), n_real, n, (const double*)L, ldl, (const double*)Minv, ldm, (const double*)y,
+                                           (double*)u, (double*)alpha, (double*)work, out),
+             pg_alpha_nlml_async_t<float>(h, ST(stream), n_real, n, (const float*)L, ldl, (const float*)Minv, ldm, (const float*)y,
+                                          (float*)u, (float*)alpha, (float*)work, out));
+}
+
 int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const void* y, const void* alpha, double* out,
                   void* stream) {
+    JOIN(h, stream);
     NEED(h && L && y && alpha && out, "null pointer");
     DISPATCH(dtype,
              pg_nlml_value_t<double>(ST(stream), n, (const double*)L, ldl, (const double*)y, (const double*)alpha, out),
@@ -279,6 +316,7 @@ long pg_nlml_grad_worksize(int n, int nhp) { return pg_nlml_grad_worksize_impl(n
 int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
                  const void* Kinv, long ldk, const void* alpha, double* grad, int nhp, double* work, long lwork,
                  void* stream) {
+    JOIN(h, stream);
     NEED(h && hp && X && Kinv && alpha && grad && work, "null pointer");
     if (check_spec(spec, __func__)) return -1;
     DISPATCH(dtype,
@@ -290,6 +328,7 @@ int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* h
 
 int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv, long ldm,
                       const void* alpha, void* mean, void* q, double kss, void* work, void* stream) {
+    JOIN(h, stream);
     NEED(h && Ks && alpha && mean && work, "null pointer");
     NEED(!q || Minv, "variance needs Minv");
     DISPATCH(dtype,
@@ -301,6 +340,7 @@ int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* 
 
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks, long ldks,
                   void* V, long ldv, void* stream) {
+    JOIN(h, stream);
     NEED(h && Minv && Ks && V, "null pointer");
     DISPATCH(dtype,
              pg_trmm_lower_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Minv, ldm, (const double*)Ks, ldks,
@@ -311,6 +351,7 @@ int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv
 
 int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc, int lower_only,
                    void* stream) {
+    JOIN(h, stream);
     NEED(h && V && C, "null pointer");
     DISPATCH(dtype, pg_syrk_tn_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)V, ldv, (double*)C, ldc, lower_only),
              pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc, lower_only));
@@ -319,6 +360,7 @@ int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, 
 int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
                          int is_first, int accumulate, double* out, long ldo, double* beta_out, double* prec_out,
                          void* stream) {
+    JOIN(h, stream);
     NEED(h && mean_c && var_c && var_g && out, "null pointer");
     NEED(ldo >= m, "ldo < m");
     DISPATCH(dtype,
@@ -330,6 +372,7 @@ int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, cons
 
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
                     void* mean, void* var, double* beta0, double* prec0, void* stream) {
+    JOIN(h, stream);
     NEED(h && sums && mean_g && var_g && mean && var, "null pointer");
     DISPATCH(dtype,
              pg_grbcm_finish_t<double>(ST(stream), m, sums, lds, (const double*)mean_g, (const double*)var_g, (double*)mean,
@@ -340,6 +383,7 @@ int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds,
 
 int pg_grbcm_weighted_prec(pg_handle h, int dtype, int m, int m_pad, const void* P, long ldp, const double* beta, void* acc,
                            long lda, int accumulate, void* stream) {
+    JOIN(h, stream);
     NEED(h && P && beta && acc, "null pointer");
     NEED(m_pad >= m && ldp >= m && lda >= m_pad, "inconsistent sizes");
     DISPATCH(dtype, pg_weighted_prec_t<double>(ST(stream), m, m_pad, (const double*)P, ldp, beta, (double*)acc, lda, accumulate),
@@ -347,12 +391,14 @@ int pg_grbcm_weighted_prec(pg_handle h, int dtype, int m, int m_pad, const void*
 }
 
 int pg_symmetrize(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
+    JOIN(h, stream);
     NEED(h && A, "null pointer");
     DISPATCH(dtype, pg_symmetrize_t<double>(ST(stream), n, (double*)A, lda), pg_symmetrize_t<float>(ST(stream), n, (float*)A, lda));
 }
 
 int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,
                          const void* cov, long ldc, void* mean, void* stream) {
+    JOIN(h, stream);
     NEED(h && sums && mean_g && var_g && cov && mean, "null pointer");
     DISPATCH(dtype,
              pg_grbcm_finish_full_t<double>(ST(stream), m, sums, lds, (const double*)mean_g, (const double*)var_g,
@@ -363,6 +409,7 @@ int pg_grbcm_finish_full(pg_handle h, int dtype, int m, const double* sums, long
 
 int pg_sqdist_argmin(pg_handle h, int dtype, const void* X, long ldx, int n, const void* C, long ldc, int m, int d, void* D,
                      long ldd, int* idx, void* stream) {
+    JOIN(h, stream);
     NEED(h && X && C && (D || idx), "null pointer");
     DISPATCH(dtype,
              pg_centres<double>(ST(stream), (const double*)X, ldx, n, (const double*)C, ldc, m, d, (double*)D, ldd, idx),
@@ -370,6 +417,7 @@ int pg_sqdist_argmin(pg_handle h, int dtype, const void* X, long ldx, int n, con
 }
 
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream) {
+    JOIN(h, stream);
     NEED(h && A, "null pointer");
     DISPATCH(dtype, pg_tril_t<double>(ST(stream), n, (double*)A, lda), pg_tril_t<float>(ST(stream), n, (float*)A, lda));
 }
@@ -402,6 +450,7 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
 }
 
 int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream) {
+    JOIN(h, stream);
     NEED(h && A && info, "null pointer");
     DISPATCH(dtype, pg_leaf<double>(ST(stream), (double*)A, lda, (double*)inv, ldi, info, 0, ablate),
              pg_leaf<float>(ST(stream), (float*)A, lda, (float*)inv, ldi, info, 0, ablate));
@@ -409,6 +458,7 @@ int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, 
 
 int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,
                 const void* B, long ldb, double beta, void* C, long ldc, int tri, int klo, int khi, void* stream) {
+    JOIN(h, stream);
     NEED(h && A && B && C, "null pointer");
     NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
              variant == GEMM_TT_128 || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_NT_32x64 ||

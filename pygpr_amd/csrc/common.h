@@ -25,6 +25,7 @@ struct pg_ctx {
     int lookahead;            // 0 disables the two-stream Cholesky (default 1)
     int nbo;                  // outer panel of the Cholesky; 0 = chosen from n (pg_set_outer_panel / PG_NBO)
     int panel_mode;           // how the rows below an outer panel ride its 128-column steps (linalg.hip, PG_PANEL_MODE)
+    int side_pending;         // side-stream work (pg_alpha_nlml_async) that the next reader of its outputs must wait for: ev[5]
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;
     double prof_ms;

@@ -8,6 +8,9 @@ long pg_potrs_vec_worksize_impl(int n);
 template <typename T> int pg_logdet_t(hipStream_t, int n, const T* L, long ldl, double* out);
 template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);
 template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work);
+template <typename T>
+int pg_alpha_nlml_async_t(pg_ctx*, hipStream_t, int n_real, int n, const T* L, long ldl, const T* Minv, long ldm, const T* y, T* u,
+                          T* alpha, T* work, double* out);
 template <typename T> int pg_nlml_value_t(hipStream_t, int n, const T* L, long ldl, const T* y, const T* alpha, double* out);
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx*, hipStream_t, int n, int m, const T* Ks, long ldks, const T* M, long ldm, const T* alpha,

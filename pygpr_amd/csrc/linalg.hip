@@ -272,6 +272,20 @@ __global__ __launch_bounds__(256) void nlml_value_kernel(const T* __restrict__ L
     if (tid == 0) out[0] = red[0] + red[1] + red[2] + red[3] + 0.5 * (double)n * 1.83787706640934548356;  // log 2pi
 }
 
+// out[0] = 1/2 y^T alpha + 1/2 logdet + n/2 log 2pi   (the NLML from a log-determinant computed earlier)
+template <typename T>
+__global__ __launch_bounds__(256) void nlml_finish_kernel(const T* __restrict__ y, const T* __restrict__ alpha, int n,
+                                                          const double* __restrict__ logdet, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += 0.5 * (double)y[i] * (double)alpha[i];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[0] = red[0] + red[1] + red[2] + red[3] + 0.5 * logdet[0] + 0.5 * (double)n * 1.83787706640934548356;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void grbcm_terms_kernel(const T* __restrict__ mean_c, const T* __restrict__ var_c,
                                                           const T* __restrict__ var_g, int m, int is_first,
@@ -691,6 +705,32 @@ int pg_nlml_value_t(hipStream_t st, int n, const T* L, long ldl, const T* y, con
     return 0;
 }
 
+// alpha = Minv^T (Minv y) and the NLML, on the handle's side stream: the two triangular mat-vecs are HBM-bound (2 x 8 n^2 / 2 B)
+// and overlap with the MFMA-bound L^-T L^-1 the caller enqueues next.  The log-determinant is taken on the caller's stream
+// first (K^-1 is about to overwrite the factor).  ctx->side_pending makes the next entry point that may read alpha / out wait.
+template <typename T>
+int pg_alpha_nlml_async_t(pg_ctx* ctx, hipStream_t st, int n_real, int n, const T* L, long ldl, const T* Minv, long ldm, const T* y,
+                          T* u, T* alpha, T* work, double* out) {
+    if (n <= 0 || n % PG_PAD) { pg_set_error("pg_alpha_nlml_async: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, n_real, out + 1);
+    LAUNCH_CHECK();
+    hipStream_t side = (ctx->lookahead && !ctx->prof_on) ? ctx->aux : st;
+    if (side != st) {
+        PG_CHECK(hipEventRecord(ctx->ev[4], st));
+        PG_CHECK(hipStreamWaitEvent(side, ctx->ev[4], 0));
+    }
+    int rc;
+    if ((rc = pg_trmv_t<T>(ctx, side, n, Minv, ldm, 0, y, u, work))) return rc;
+    if ((rc = pg_trmv_t<T>(ctx, side, n, Minv, ldm, 1, u, alpha, work))) return rc;
+    hipLaunchKernelGGL(nlml_finish_kernel<T>, dim3(1), dim3(256), 0, side, y, alpha, n_real, out + 1, out);
+    LAUNCH_CHECK();
+    if (side != st) {
+        PG_CHECK(hipEventRecord(ctx->ev[5], side));
+        ctx->side_pending = 1;
+    }
+    return 0;
+}
+
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, long ldks, const T* M, long ldm,
                         const T* alpha, T* mean, T* q, double kss, T* work) {
@@ -777,6 +817,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
     template int pg_logdet_t<T>(hipStream_t, int, const T*, long, double*);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
+    template int pg_alpha_nlml_async_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, T*, T*, double*); \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \
                                         T*, double, T*);                                                               \

@@ -64,6 +64,7 @@ class MLE(Loss):
                 "vwork": ops.empty((n_pad // 256) * n_pad, dtype=dtype),
                 "gwork": ops.empty(ops.nlml_grad_worksize(n, nhp), dtype=torch.float64),
                 "out": ops.zeros(1 + nhp, dtype=torch.float64),
+                "val": ops.zeros(2, dtype=torch.float64),
             }
         return self._buf
 
@@ -117,11 +118,11 @@ class MLE(Loss):
             elif want_grad:
                 ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
                 ops.potrf_trtri(a, buf["invd"], buf["info"], m)      # Cholesky + L^-1, overlapped inside the library
-                ops.trmv(m, e.y, buf["u"], 0)                       # u = L^-1 y
-                ops.trmv(m, buf["u"], buf["alpha"], 1, buf["vwork"])  # alpha = L^-T u
-                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
-                ops.lauum(m, a)                                     # a <- K^-1 (lower)
-                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
+                # alpha = L^-T (L^-1 y) and the NLML value on the library's side stream, beside K^-1 = L^-T L^-1 (lower, over a)
+                ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, buf["val"])
+                ops.lauum(m, a)
+                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])   # waits for the side stream
+                out[0:1].copy_(buf["val"][0:1])
             else:
                 ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
                 ops.potrf(a, buf["invd"], buf["info"])

@@ -142,6 +142,11 @@ class OracleOps:
         out[0] = 0.5 * float(_np(y)[:n].astype(np.float64) @ _np(alpha)[:n].astype(np.float64)) \
             + float(np.log(d).sum()) + 0.5 * n * np.log(2 * np.pi)
 
+    def alpha_nlml_async(self, chol, minv, y, u, alpha, work, n, out):
+        self.trmv(minv, y, u, 0)
+        self.trmv(minv, u, alpha, 1)
+        self.nlml_value(chol, y, alpha, n, out)
+
     def nlml_grad_worksize(self, n, nhp):
         return 1
 
