@@ -189,6 +189,10 @@ int pg_set_outer_panel(pg_handle h, int columns);
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
 
+/* how many outer panels of the handle's LAST pg_potrf / pg_potrf_trtri ran on the flag-coupled chain (0: classic chain only;
+ * the coupled chain needs the look-ahead schedule and a caller stream that is a real non-blocking stream) -- tests / diagnostics */
+int pg_last_coupled_panels(pg_handle h);
+
 /* one 128x128 Cholesky leaf (factor + inverse) on its own; ablate != 0 skips phases -- timing diagnostics only */
 int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream);
 

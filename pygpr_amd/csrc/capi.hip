@@ -23,6 +23,7 @@ static bool g_atexit_registered = false;
 
 static void release_ctx(pg_ctx* h) {
     (void)hipStreamDestroy(h->aux);
+    if (h->rows) (void)hipStreamDestroy(h->rows);
     if (h->upd) (void)hipStreamDestroy(h->upd);
     if (h->bg) (void)hipStreamDestroy(h->bg);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -88,7 +89,18 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     p.tri = tri; p.klo = klo; p.khi = khi;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
     p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
-    return pg_gemm<T>(h, ST(stream), variant, p);
+    // PG_RAW_STREAM=upd|bg (measurement only): run the product on one of the handle's CU-masked streams instead
+    static const char* rs = getenv("PG_RAW_STREAM");
+    hipStream_t on = ST(stream);
+    if (rs && rs[0] == 'u' && h->upd) on = h->upd;
+    if (rs && rs[0] == 'b' && h->bg) on = h->bg;
+    if (on == ST(stream)) return pg_gemm<T>(h, on, variant, p);
+    PG_CHECK(hipEventRecord(h->ev[4], ST(stream)));
+    PG_CHECK(hipStreamWaitEvent(on, h->ev[4], 0));
+    const int rc = pg_gemm<T>(h, on, variant, p);
+    PG_CHECK(hipEventRecord(h->ev[5], on));
+    PG_CHECK(hipStreamWaitEvent(ST(stream), h->ev[5], 0));
+    return rc;
 }
 
 extern "C" {
@@ -108,6 +120,8 @@ int pg_create(pg_handle* h) {
     int prio_lo = 0, prio_hi = 0;
     PG_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     PG_CHECK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
+    c->rows = nullptr;
+    c->last_coupled = 0;
     c->lookahead = 1;
     {
         const char* e = getenv("PG_NBO");
@@ -143,6 +157,27 @@ int pg_create(pg_handle* h) {
         for (int cu = 0; cu < bgcus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
         if (c->upd && hipExtStreamCreateWithCUMask(&c->bg, (uint32_t)words, mask) != hipSuccess) {
             c->bg = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    {   // rows stream of the flag-coupled chain; PG_ROWS_KIND = none | plain | hi | mask (experiment)
+        const char* kind = getenv("PG_ROWS_KIND");
+        if (!kind) kind = "none";
+        hipError_t e = hipSuccess;
+        if (kind[0] == 'n') c->rows = nullptr;
+        else if (kind[0] == 'h') e = hipStreamCreateWithPriority(&c->rows, hipStreamNonBlocking, prio_hi);
+        else if (kind[0] == 'm') {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            PG_CHECK(hipGetDevice(&dev));
+            PG_CHECK(hipGetDeviceProperties(&prop, dev));
+            uint32_t mask[64];
+            for (int i = 0; i < 64; ++i) mask[i] = 0;
+            for (int cu = 0; cu < prop.multiProcessorCount && cu < 2048; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+            e = hipExtStreamCreateWithCUMask(&c->rows, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask);
+        } else e = hipStreamCreateWithFlags(&c->rows, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            c->rows = nullptr;
             (void)hipGetLastError();
         }
     }
@@ -440,6 +475,10 @@ int pg_profile(pg_handle h, int on) {
     if (on) { h->prof_flops = 0; h->prof_ms = 0; h->prof_launches = 0; }
     h->prof_on = on;
     return 0;
+}
+int pg_last_coupled_panels(pg_handle h) {
+    if (!h) return -1;
+    return h->last_coupled;
 }
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
     NEED(h, "null handle");

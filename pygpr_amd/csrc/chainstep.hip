@@ -1,0 +1,266 @@
+// Flag-coupled chain of the Cholesky's latency-bound tail.
+//
+// In the classic chain every 128-column step is three dependent launches on one stream (U: bring the block column up to date,
+// leaf: factor + invert the diagonal tile, T: solve the rows below), each behind the previous one's completion and a launch gap:
+// 62 us per step at n <= 8192, of which the leaf is 34.  Here a step is TWO kernels on two streams that are both resident before
+// their inputs exist and hand over through flags in device memory (agent-scope, cdna_hip_programming.md guideline 16):
+//
+//   leaf stream : leaf(k)   waits diag[k] == NCRIT, factors tile (k, k), stores L_kk and inv_k, releases done[k]
+//   rows stream : rows(k)   one workgroup per 32 / 64 rows below tile (k, k):
+//                   before done[k]:  acc = X[rows, o0:k0] X[blk k+1, o0:k0]^T      (the next block column's update by the panel's
+//                                    earlier columns: everything it reads is final since rows(k-1) ended)
+//                   after  done[k]:  X[rows, blk k] = A[rows, blk k] inv_k^T        (T)
+//                                    the NCRIT workgroups owning block row k+1 publish their X rows (brow[k] += 1)
+//                   after  brow[k] == NCRIT:  acc += X[rows, blk k] X[blk k+1, blk k]^T;  A[rows, blk k+1] -= acc   (U)
+//                                    the NCRIT workgroups owning tile (k+1, k+1) publish it (diag[k+1] += 1)
+//
+// so between two leaves lie one K = 128 solve, one K = 128 product and three flag hops instead of two full launches, and the
+// long part of the update runs while the leaf does.  Host enqueue order is leaf(k), rows(k), leaf(k+1), ...: a topological order,
+// so the pair makes progress even if the two streams were served by one hardware queue.  Every spin is bounded: on expiry a
+// sticky timeout word ends all later spins at once and *info is set to -1 (the caller sees a failed factorisation, not a hang).
+// Every kernel performs all of its signals whatever it saw (bad pivot, timeout), so nothing downstream waits for ever.
+#include "chainstep.h"
+
+#define NB 128
+#define CS_NTH 512
+#define CS_KC 32
+#define CS_CLD (CS_KC + 2)
+#define CS_XLD (NB + 2)
+#define CS_SPIN_LIMIT (1u << 22)     // x (s_sleep + one L2 round trip) = a few seconds
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ bool cs_spin_ge(int* flag, int want, int* tmo) {   // ONE lane
+    for (unsigned it = 0;; ++it) {
+        if (__hip_atomic_load(flag, RLX_AGENT) >= want) return true;
+        if ((it & 31u) == 31u && __hip_atomic_load(tmo, RLX_AGENT) != 0) return false;
+        if (it > CS_SPIN_LIMIT) {
+            __hip_atomic_store(tmo, 1, RLX_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// Whole workgroup: wait until *flag >= want, then make the publisher's bytes loadable (one lane's agent-scope acquire drops this
+// CU's L1 lines; its wait holds the barrier for the invalidate).
+__device__ __forceinline__ void cs_wg_wait(int* flag, int want, int* tmo, int* info) {
+    if (threadIdx.x == 0) {
+        if (!cs_spin_ge(flag, want, tmo)) atomicCAS(info, 0, -1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// Whole workgroup, after its write-through (sc1) stores: every storing wave drains, one lane adds to the counter.
+__device__ __forceinline__ void cs_wg_signal(int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1, RLX_AGENT);
+}
+
+template <typename T> __device__ __forceinline__ void st_wt(T* p, T v);   // write-through store (sc1)
+template <> __device__ __forceinline__ void st_wt<double>(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), RLX_AGENT);
+}
+template <> __device__ __forceinline__ void st_wt<float>(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), RLX_AGENT);
+}
+
+// acc[MI][2] += Aop[ROWS x K] B[128 x K]^T for this wave's 16 MI x 32 tile (waves: 2 row groups x 4 column groups).
+//   A_LDS false: A rows from global (Ag, lda), staged;  true: A = the workgroup's LDS tile Xl[ROWS][CS_XLD], columns 0 .. K-1
+//   B from global (Bg, ldb), staged in K chunks of 32 with the next chunk's loads in flight during the MFMAs.
+//   lower_b: B[n][k] = 0 for k > n (the leaf's inverse): chunks past the wave's last column are skipped.
+template <typename T, int MI, bool A_LDS>
+__device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[MI][2], const T* __restrict__ Ag, long lda, const T* Xl,
+                                      const T* __restrict__ Bg, long ldb, int K, bool lower_b, T* As, T* Bs) {
+    constexpr int ROWS = 32 * MI;
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int VPR = CS_KC / VE;                              // 16-byte vectors per row of a chunk
+    constexpr int NVB = NB * VPR, NVA = ROWS * VPR;
+    constexpr int UB = (NVB + CS_NTH - 1) / CS_NTH, UA = (NVA + CS_NTH - 1) / CS_NTH;
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave >> 2, cg = wave & 3, fr = lane & 15, fk = lane >> 4;
+    vec_t vb[UB], va[UA];
+    auto issue = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int v = tid + u * CS_NTH;
+            if (v < NVB) vb[u] = *reinterpret_cast<const vec_t*>(Bg + (long)(v / VPR) * ldb + kc + (v % VPR) * VE);
+        }
+        if (!A_LDS) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int v = tid + u * CS_NTH;
+                if (v < NVA) va[u] = *reinterpret_cast<const vec_t*>(Ag + (long)(v / VPR) * lda + kc + (v % VPR) * VE);
+            }
+        }
+    };
+    if (K > 0) issue(0);
+    for (int kc = 0; kc < K; kc += CS_KC) {
+        __syncthreads();                                          // the previous chunk's readers are done
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int v = tid + u * CS_NTH;
+            if (v < NVB) {
+                T* d = Bs + (v / VPR) * CS_CLD + (v % VPR) * VE;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) d[e] = vb[u][e];
+            }
+        }
+        if (!A_LDS) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int v = tid + u * CS_NTH;
+                if (v < NVA) {
+                    T* d = As + (v / VPR) * CS_CLD + (v % VPR) * VE;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) d[e] = va[u][e];
+                }
+            }
+        }
+        __syncthreads();
+        if (kc + CS_KC < K) issue(kc + CS_KC);
+        if (lower_b && kc > 32 * cg + 31) continue;               // wave-uniform; the barriers above are still reached
+#pragma unroll
+        for (int ks = 0; ks < CS_KC / 4; ++ks) {
+            T a[MI], b[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                a[i] = A_LDS ? Xl[(16 * MI * rg + 16 * i + fr) * CS_XLD + kc + 4 * ks + fk]
+                             : As[(16 * MI * rg + 16 * i + fr) * CS_CLD + 4 * ks + fk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(32 * cg + 16 * j + fr) * CS_CLD + 4 * ks + fk];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+        }
+    }
+}
+
+template <typename T, int MI>
+__device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, long lda, int row0, int o0, int k0, bool has_next,
+                                             bool crit, const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next, int ncrit,
+                                             int* tmo, int* info) {
+    constexpr int ROWS = 32 * MI;
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    T* Xl = reinterpret_cast<T*>(smem_raw);                      // [ROWS][CS_XLD]
+    T* As = Xl + ROWS * CS_XLD;                                  // [ROWS][CS_CLD]
+    T* Bs = As + ROWS * CS_CLD;                                  // [128][CS_CLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = wave >> 2, cg = wave & 3, fr = lane & 15;
+    T* Arow = A + (long)row0 * lda;                              // this workgroup's rows
+    const T* Brow = A + (long)(k0 + NB) * lda;                   // block row k+1
+    typename Mfma<T>::acc_t acc[MI][2], cin[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][j][r] = (T)0;
+                cin[i][j][r] = (T)0;
+            }
+    // this workgroup's block of column k -> LDS (its values are final except for the solve), and the block of column k+1
+    for (int v = tid; v < ROWS * NB / VE; v += CS_NTH) {
+        const int r = v / (NB / VE), c = (v % (NB / VE)) * VE;
+        const vec_t x = *reinterpret_cast<const vec_t*>(Arow + (long)r * lda + k0 + c);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) Xl[r * CS_XLD + c + e] = x[e];
+    }
+    if (has_next) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cin[i][j][r] = Arow[(long)(16 * MI * rg + 16 * i + Mfma<T>::row(lane, r)) * lda + k0 + NB + 32 * cg + 16 * j + fr];
+        // the panel's earlier columns
+        cs_mm<T, MI, false>(acc, Arow + o0, lda, Xl, Brow + o0, lda, k0 - o0, false, As, Bs);
+    }
+    cs_wg_wait(done_k, 1, tmo, info);
+    // T: rows x inv_k^T
+    typename Mfma<T>::acc_t t[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[i][j][r] = (T)0;
+    cs_mm<T, MI, true>(t, nullptr, 0, Xl, inv, NB, NB, true, As, Bs);
+    __syncthreads();                                             // every wave has read its rows of Xl
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * MI * rg + 16 * i + Mfma<T>::row(lane, r), cc = 32 * cg + 16 * j + fr;
+                Xl[rr * CS_XLD + cc] = t[i][j][r];
+                T* g = Arow + (long)rr * lda + k0 + cc;
+                if (crit) st_wt<T>(g, t[i][j][r]);
+                else *g = t[i][j][r];
+            }
+    if (crit) cs_wg_signal(brow_k);
+    if (!has_next) return;
+    cs_wg_wait(brow_k, ncrit, tmo, info);                        // also orders this workgroup's Xl stores before the loads below
+    cs_mm<T, MI, true>(acc, nullptr, 0, Xl, Brow + k0, lda, NB, false, As, Bs);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T* g = Arow + (long)(16 * MI * rg + 16 * i + Mfma<T>::row(lane, r)) * lda + k0 + NB + 32 * cg + 16 * j + fr;
+                const T v = cin[i][j][r] - acc[i][j][r];
+                if (crit) st_wt<T>(g, v);
+                else *g = v;
+            }
+    if (crit) cs_wg_signal(diag_next);
+}
+
+// grid = m / 32 workgroups (m = rows below tile (k, k)), 32 rows each; the first four own block row k+1 (what the next leaf waits
+// for).  77 KB of LDS and at most 128 VGPRs: a workgroup fits beside one resident 128 x 128 GEMM block of the trailing update.
+// (64-row workgroups for the rows further down halve the re-reads of block row k+1 but need 119 KB: they would only ever start
+// on an empty CU.)
+template <typename T>
+__global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
+                                                               const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
+                                                               int* tmo, int* info) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int w = blockIdx.x;
+    cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 32 * w, o0, k0, has_next != 0, w < 4, inv, done_k, brow_k, diag_next, 4, tmo, info);
+}
+
+__global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(flag, value, RLX_AGENT); }
+
+template <typename T>
+int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
+               int* diag_next, int* tmo, int* info) {
+    const int m = n - k0 - NB;
+    if (m <= 0 || m % NB) { pg_set_error("pg_rowstep: %d rows below the tile", m); return -2; }
+    const size_t lds = (size_t)(32 * CS_XLD + 32 * CS_CLD + NB * CS_CLD) * sizeof(T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_rowstep_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(m / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
+                       brow_k, diag_next, tmo, info);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, int*, int*);
+template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, int*, int*);
+
+int pg_flagset(hipStream_t st, int* flag, int value) {
+    hipLaunchKernelGGL(pg_flagset_kernel, dim3(1), dim3(1), 0, st, flag, value);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}

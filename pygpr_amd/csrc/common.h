@@ -16,6 +16,7 @@ typedef float pg_f4 __attribute__((ext_vector_type(4)));
 
 struct pg_ctx {
     hipStream_t aux;          // look-ahead / panel stream (highest priority, non-blocking)
+    hipStream_t rows;         // rows stream of the flag-coupled chain (chainstep.hip; highest priority, non-blocking)
     hipStream_t bg;           // background stream (same CU mask as upd): L^-1 of the leading half during potrf's tail
     hipStream_t upd;          // trailing-update stream: CU mask leaves PG_RESERVED_CUS compute units to the panel chain
                               // (the 128x128 leaf needs a whole CU's LDS and starves beside a chip-filling SYRK)
@@ -24,6 +25,7 @@ struct pg_ctx {
     int npool;
     int lookahead;            // 0 disables the two-stream Cholesky (default 1)
     int nbo;                  // outer panel of the Cholesky; 0 = chosen from n (pg_set_outer_panel / PG_NBO)
+    int last_coupled;         // panels the last factorisation ran on the flag-coupled chain (chainstep.hip); tests / diagnostics
     int panel_mode;           // how the rows below an outer panel ride its 128-column steps (linalg.hip, PG_PANEL_MODE)
     int side_pending;         // side-stream work (pg_alpha_nlml_async) that the next reader of its outputs must wait for: ev[5]
     int prof_on;              // profiling of the GEMM core (bench roofline leg)

@@ -13,6 +13,7 @@
 // block is 4096 MFMA cycles per wave against 8 ds_read_b64 per k-step: the loop is MFMA-bound by construction.
 #include "gemm.h"
 #include <cstdlib>
+#include <cstdio>
 
 #define BK 16
 
@@ -241,16 +242,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
     }
 }
 
+// LDS request floor of the next launches (pg_gemm sets it): 84 KB leaves room for ONE workgroup of the launch per CU, so half of
+// every CU's registers and LDS stays free for the kernels of another stream
+static thread_local size_t g_lds_floor = 0;
+#define HALF_CU_LDS (84 * 1024)
+
 template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
 static int launch(hipStream_t st, const GemmP<T>& p) {
     typedef Stage<T, BM, !TA, BKT, 64 * NW> SA;
     typedef Stage<T, BN, TB, BKT, 64 * NW> SB;
-    const size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T);
+    const size_t lds = std::max<size_t>(2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T), g_lds_floor);
     static bool attr_done = false;
     auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI, BKT, NW>;
     if (!attr_done) {
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)std::max<size_t>(2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T), HALF_CU_LDS)));
         attr_done = true;
     }
     if (p.M % BM || p.N % BN || p.K % BKT || (p.tri && BM != BN)) {
@@ -297,6 +303,9 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     const bool w4 = w4env || sizeof(T) == 4 || (variant == GEMM_NN_128_SS && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
+    static const int bg_half = getenv("PG_BG_HALF") ? atoi(getenv("PG_BG_HALF")) : 0;
+    static const int upd_half = getenv("PG_UPD_HALF") ? atoi(getenv("PG_UPD_HALF")) : 0;
+    g_lds_floor = (ctx && ((bg_half && st == ctx->bg) || (upd_half && st == ctx->upd))) ? HALF_CU_LDS : 0;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;
@@ -318,6 +327,14 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;
+    {   // PG_GEMM_LOG=<file>: one line per launch (variant, waves, shape, flops) in launch order, for tools/trace_util.py
+        static FILE* logf = getenv("PG_GEMM_LOG") ? fopen(getenv("PG_GEMM_LOG"), "w") : nullptr;
+        if (logf) {
+            fprintf(logf, "%d %d %d %d %d %d %d %.0f\n", variant, (int)sizeof(T), w4 ? 4 : 8, p.M, p.N, p.K, p.batch,
+                    pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch));
+            fflush(logf);
+        }
+    }
     if (prof) {
         PG_CHECK(hipEventRecord(ctx->ev[7], st));
         PG_CHECK(hipEventSynchronize(ctx->ev[7]));

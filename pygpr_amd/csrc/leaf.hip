@@ -329,9 +329,8 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
 // Waves 4-11 meanwhile run the deferred trailing update of the previous micro-panel and the inverse's block row, as before.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                                       int* __restrict__ info, int col0, int ablate) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
+                                           int* __restrict__ info, int col0, int ablate) {
     T* S = reinterpret_cast<T*>(smem_raw);
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
     int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
@@ -474,6 +473,62 @@ __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long l
     __syncthreads();
     store_inv_rows(112, 128);
 }
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
+                                                       int* __restrict__ info, int col0, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    leaf2_body<T>(smem_raw, A, lda, inv, ldi, info, col0, ablate);
+}
+
+// The leaf of the flag-coupled chain (chainstep.hip): resident before its tile exists.  Waits until the `want` workgroups that
+// own the tile have published it (*ready, write-through stores on their side), factors, then releases *done: plain stores, every
+// wave drained, one agent-scope release (this CU's XCD is reserved for the chain: its L2 holds little else that is dirty).
+// *done is set on every path (bad pivot, earlier failure, timeout): the rows below wait for it.
+template <typename T>
+__global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
+                                                        int col0, int* ready, int want, int* done, int* tmo) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (threadIdx.x == 0) {
+        for (unsigned it = 0;; ++it) {
+            if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            if ((it & 31u) == 31u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (it > (1u << 22)) {
+                __hip_atomic_store(tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicCAS(info, 0, -1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    leaf2_body<T>(smem_raw, A, lda, inv, NB, info, col0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
+                                       int* tmo) {
+    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(pg_leaf2s_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, int*);
+template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, int*);
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;

@@ -12,6 +12,7 @@
 // potrs  : blocked substitution with the 128x128 diagonal inverses, one fused kernel per block step.
 #include "gemm.h"
 #include "leaf.h"
+#include "chainstep.h"
 #include "linalg.h"
 #include <cmath>
 #include <cstdlib>
@@ -481,8 +482,30 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // and half-width panels over the last 4096 / 8192 columns -- both within +-0.2 ms at n = 12288 / 16384: the schedule
     // is throughput-bound on the whole (the chain and the updates share the chip at 62-77 % MFMA use per CU), so shifting
     // work between its two streams does not shorten it.
+    // flag-coupled chain (chainstep.hip) for the panels with at most `sync_rows` rows left -- the chain-bound tail: leaves on the
+    // panel stream, the rows below them on the handle's rows stream, coupled by flags in device memory instead of launches.
+    // Its rows kernels update a block column by the previous panel too (the window of the left-looking product starts there), so
+    // the per-panel update Sa disappears from the critical path; panels are at most 512 wide there to keep that product
+    // shorter than a leaf.
+    // Measured (MI355X, fp64, build + factor): n = 4096 2.28 -> 1.77 ms, 8192 6.30 -> 5.37, 16384 30.75 -> 29.42 with the last 8192
+    // rows coupled (2048: 30.41, 4096: 30.03, 6144: 29.62, 12288: 30.14, all: 31.48 -- while the trailing update still fills the
+    // chip the resident rows workgroups hold the slots it needs).  With the background inverse of the fused call running, the
+    // rows workgroups starve beside its long tiles: n = 16384 fused 51.5 -> 52.5 ms, so above 8192 the fused call keeps the classic
+    // chain (n = 8192 fused: 8.87 -> 8.16).
+    static const int sync_env = getenv("PG_SYNC_ROWS") ? atoi(getenv("PG_SYNC_ROWS")) : -1;
+    const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && n > 8192) ? 0 : 8192);
+    // The rows stream is the CALLER's stream (idle while the factorisation runs on the handle's streams) -- a further stream of
+    // the handle's own costs the whole look-ahead 60 % (stream count) -- and it must be a real non-blocking stream: work
+    // on the null stream would wait for the CU-masked update stream, which can only be created blocking.
+    hipStream_t rows_stream = ctx->rows;
+    if (!rows_stream && st != nullptr && st != hipStreamLegacy && st != hipStreamPerThread) {
+        unsigned int fl = 0;
+        if (hipStreamGetFlags(st, &fl) == hipSuccess && (fl & hipStreamNonBlocking)) rows_stream = st;
+        else (void)hipGetLastError();
+    }
+    const bool want_cp = ctx->lookahead && !ctx->prof_on && rows_stream && sync_rows > 0 && ctx->panel_mode == 0;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
-    for (int c = 0; c < n; c += NBO) pb.push_back(c);
+    for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, 512) : NBO) pb.push_back(c);
     pb.push_back(n);
     const int npan = (int)pb.size() - 1;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
@@ -503,20 +526,53 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     const long NBW = std::min<long>(n, NBO_MAX);
     T* Wt = invD + (long)n * NB;          // inverse of the current panel's triangular factor, leading dimension = panel width
     T* Xs = Wt + NBW * NBW;               // the panel's solved rows (out of place), leading dimension = panel width
+    const bool coupled = la && want_cp;
+    int o_s = npan;                             // first coupled panel
+    if (coupled)
+        for (int o = 0; o < npan; ++o)
+            if (n - pb[o] <= sync_rows) { o_s = o; break; }
+    ctx->last_coupled = npan - o_s;
+    const int nblk = n / NB;
+    int* f_diag = reinterpret_cast<int*>(Xs);   // [nblk] workgroups that have published tile (b, b);  the work area is ours
+    int* f_done = f_diag + nblk;                // [nblk] leaf b has stored L_bb and its inverse
+    int* f_brow = f_done + nblk;                // [nblk] workgroups that have published X[block row b+1, block column b]
+    int* f_tmo = f_brow + nblk;                 // sticky time-out word
+    if (o_s < npan) {
+        PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((3 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
+    }
     for (int o = 0; o < npan; ++o) {
         const int o0 = pb[o], oend = pb[o + 1];
-        // Chain(o): left-looking 128-column steps (U, leaf, T).
-        // panel modes (ctx->panel_mode, PG_PANEL_MODE): 0 (default) = every 128-column step works on all rows below;
-        // 1 = recursive panel: the steps only touch the panel's own triangle, then its factor is inverted (recursive
-        // doubling) and ALL rows below are solved as one full-tile product X = A[oend:n, panel] inv(L_panel)^T.  Measured
-        // slower with one launch per step (n = 16384: 34.4 vs 32.7 ms, n = 8192: 8.2 vs 7.2): the triangle's short launches
-        // and the six of the inverse cost more latency than the skinny products lose.  Kept behind the switch.
-        // (A split chain -- the rows below the panel on a further stream behind one event per step -- was measured and
-        // removed: a fifth stream in the process costs the look-ahead 20 % whether it is used or not.)
-        const int mode = (oend < n) ? ctx->panel_mode : 0;
+        const bool cp = o >= o_s;
+        if (cp) {
+            hipStream_t rs = rows_stream;
+            if (o == o_s) {
+                // everything so far that touched these columns ran on the panel stream or was waited for there
+                if ((rc = pg_flagset(ps, f_diag + o0 / NB, 4))) return rc;
+                if ((rc = pool_event(ctx, 4 + 2 * npan, &ev))) return rc;
+                PG_CHECK(hipEventRecord(ev, ps));
+                PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+            }
+            for (int k0 = o0; k0 < oend; k0 += NB) {
+                const int kb = k0 / NB;
+                T* inv = invD + (long)kb * NB * NB;
+                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, 4, f_done + kb, f_tmo))) return rc;
+                if (n - k0 - NB <= 0) break;
+                const int c = k0 + NB;                       // the block column this step brings up to date
+                const int oc = c < oend ? o : o + 1;         // its panel
+                const int wstart = oc == o_s ? pb[o_s] : pb[oc - 1];   // the classic part applied the panel before the first coupled one
+                if (c == oend && oc >= 2) {                  // first touch of panel oc: Sb(oc - 2) wrote these columns last
+                    if ((rc = pool_event(ctx, 2 + 2 * (oc - 2) + 1, &ev))) return rc;
+                    PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+                }
+                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, f_tmo, info)))
+                    return rc;
+            }
+        }
+        static const int mode1_rows = getenv("PG_MODE1_ROWS") ? atoi(getenv("PG_MODE1_ROWS")) : 0;
+        const int mode = (oend < n && n - o0 > mode1_rows) ? ctx->panel_mode : 0;
         const bool v2 = mode == 1;
         const int tri_end = v2 ? oend : n;     // last row the panel stream's 128-column steps touch
-        for (int k0 = o0; k0 < oend; k0 += NB) {
+        for (int k0 = o0; k0 < oend && !cp; k0 += NB) {
             T* Akk = A + (long)k0 * lda + k0;
             T* inv = invD + (long)(k0 / NB) * NB * NB;
             if (k0 > o0) {   // U: bring this column block up to date with the panel's earlier columns
@@ -553,9 +609,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             LAUNCH_CHECK();
         }
         if (oend >= n) break;
+        hipStream_t cs = cp ? rows_stream : ps; // the stream whose completion means Chain(o) is done
         if (la) {
             if ((rc = pool_event(ctx, 2 + 2 * o, &ev))) return rc;       // ev_chain[o]
-            PG_CHECK(hipEventRecord(ev, ps));
+            PG_CHECK(hipEventRecord(ev, cs));
             PG_CHECK(hipStreamWaitEvent(us, ev, 0));
             if (split && oend == split) {   // columns [0, split) of L are final in every row
                 PG_CHECK(hipStreamWaitEvent(ctx->bg, ev, 0));
@@ -564,7 +621,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             }
         }
         const int o2 = (o + 2 <= npan) ? pb[o + 2] : n;   // first column right of panel o+1
-        {   // Sa(o): panel o+1's columns -= panel o
+        if (!cp) {   // Sa(o): panel o+1's columns -= panel o   (coupled panels: part of the rows kernels' left-looking product)
             GemmP<T> p = gp0<T>(); p.info = info;
             p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
             p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
@@ -573,10 +630,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             const long tiles = (long)(p.M / 128) * (p.N / 128);
             if (la && o > 0) {   // these columns were last written by Sb(o-1)
                 if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
-                PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
+                PG_CHECK(hipStreamWaitEvent(cs, ev, 0));
             }
             // (64 x 64 below 1024 large tiles; re-swept with the eight-wave 128 x 128 blocks: 256 is 0.4-0.8 ms slower at 16384)
-            if ((rc = pg_gemm<T>(ctx, la ? ps : us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            if ((rc = pg_gemm<T>(ctx, la ? cs : us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         const int m2 = n - o2;
         if (m2 > 0) {  // Sb(o)
@@ -602,6 +659,13 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
         if ((rc = pool_event(ctx, 2 + 2 * npan, &ev))) return rc;
         PG_CHECK(hipEventRecord(ev, us));
         PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+        if (o_s < npan) {   // the last leaf only waited for the workgroups that own its tile
+            if ((rc = pool_event(ctx, 5 + 2 * npan, &ev))) return rc;
+            if (rows_stream != st) {
+                PG_CHECK(hipEventRecord(ev, rows_stream));
+                PG_CHECK(hipStreamWaitEvent(st, ev, 0));
+            }
+        }
         if (split) {
             if ((rc = pool_event(ctx, 3 + 2 * npan, &ev))) return rc;
             PG_CHECK(hipEventRecord(ev, ctx->bg));

@@ -351,7 +351,7 @@ def test_potrf_solves_inverse(ops, n):
 @pytest.mark.parametrize("n", [3072, 2816])
 def test_potrf_lookahead_matches_sequential(ops, n):
     """n = 3072 spans six 512-column outer panels (2816: the last one ragged), so the two-stream look-ahead schedule
-    is active; it must give the same factor as the single-stream schedule (same arithmetic, different overlap) and
+    is active; it must give the same factor as the single-stream schedule (to rounding: see below) and
     match LAPACK."""
     rng = np.random.default_rng(33)
     a = spd(n, rng)
@@ -364,7 +364,9 @@ def test_potrf_lookahead_matches_sequential(ops, n):
         assert int(info.item()) == 0
         outs.append(np.tril(host(ad)))
     ops.set_lookahead(1)
-    assert np.array_equal(outs[0], outs[1])
+    # the flag-coupled chain of the look-ahead schedule (chainstep.hip) sums a block column's update over two panels at once:
+    # the same terms in another order, so the two factors agree to rounding, not bit for bit
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-13)
     np.testing.assert_allclose(outs[0], np.linalg.cholesky(a), atol=1e-11)
 
 
@@ -617,3 +619,113 @@ def test_grbcm_terms(ops):
     mu_ref, var_ref = orc.grbcm_finish(ref, mg, vg)
     np.testing.assert_allclose(host(mean), mu_ref, rtol=1e-12)
     np.testing.assert_allclose(host(var), var_ref, rtol=1e-12)
+
+
+# ---- flag-coupled chain (chainstep.hip): resident leaf + rows kernels handing over through device flags ------------------------
+def _potrf_on_compute_stream(ops, a, dtype=torch.float64):
+    """pg_potrf with the caller on a real non-blocking stream (the package's compute stream), which is what lets the library use
+    that stream as the second queue of the coupled chain."""
+    assert ops.stream is not None
+    ops.stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ops.stream):
+        ad = dev(a, dtype)
+        n = a.shape[0]
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        invd = ops.potrf_workspace(n, dtype)
+        ops.potrf(ad, invd, info)
+        coupled = ops.last_coupled_panels()
+    ops.stream.synchronize()
+    return ad, invd, int(info.item()), coupled
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1536, 2816, 4096, 6144])
+def test_coupled_chain_factor_matches_lapack(ops, n):
+    """Every panel of these sizes runs on the coupled chain (n <= 8192): factor and diagonal-block inverses against LAPACK."""
+    rng = np.random.default_rng(100 + n)
+    a = spd(n, rng)
+    ad, invd, info, coupled = _potrf_on_compute_stream(ops, a)
+    assert info == 0
+    assert coupled == -(-n // 512), "the coupled chain did not run"
+    chol = np.linalg.cholesky(a)
+    np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
+    blocks = host(invd[: n * 128]).reshape(n // 128, 128, 128)
+    for b in (0, n // 256, n // 128 - 1):
+        d = chol[b * 128:(b + 1) * 128, b * 128:(b + 1) * 128]
+        np.testing.assert_allclose(blocks[b], np.linalg.inv(d), atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_coupled_chain_tail_of_a_larger_matrix(ops):
+    """n = 10240: the first panels run the classic chain, the last 8192 rows the coupled one; same factor as the single-stream
+    schedule to rounding."""
+    n = 10240
+    rng = np.random.default_rng(7)
+    a = spd(n, rng)
+    ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
+    assert info == 0 and coupled == 16
+    ops.set_lookahead(0)
+    try:
+        ref = dev(a)
+        info2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.potrf(ref, ops.potrf_workspace(n, torch.float64), info2)
+        assert int(info2.item()) == 0 and ops.last_coupled_panels() == 0
+    finally:
+        ops.set_lookahead(1)
+    np.testing.assert_allclose(np.tril(host(ad)), np.tril(host(ref)), rtol=0, atol=5e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [0, 700, 2047, 3000])
+def test_coupled_chain_reports_the_first_bad_pivot_and_ends(ops, bad):
+    """A non-positive pivot inside the coupled region: info = column + 1 (LAPACK), and every resident kernel still gets its
+    flags (the call returns instead of spinning)."""
+    n = 3072
+    rng = np.random.default_rng(5)
+    a = spd(n, rng)
+    a[bad, bad] = -1.0
+    _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+    assert coupled > 0
+    assert info == bad + 1
+
+
+@pytest.mark.gpu
+def test_coupled_chain_fp32(ops):
+    n = 4096
+    rng = np.random.default_rng(11)
+    a = spd(n, rng, cond_shift=4.0)
+    ad, _, info, coupled = _potrf_on_compute_stream(ops, a, torch.float32)
+    assert info == 0 and coupled == 8
+    l = np.tril(host(ad).astype(np.float64))
+    assert np.abs(l @ l.T - a).max() / np.abs(a).max() < 5e-5
+
+
+@pytest.mark.gpu
+def test_coupled_chain_fused_inverse(ops):
+    """pg_potrf_trtri at n = 4096 on the compute stream: coupled chain + the triangular inverse behind it."""
+    n = 4096
+    rng = np.random.default_rng(13)
+    a = spd(n, rng)
+    ops.stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(ops.stream):
+        ad = dev(a)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        minv = ops.zeros(n, n)
+        ops.potrf_trtri(ad, ops.potrf_workspace(n, torch.float64), info, minv)
+        coupled = ops.last_coupled_panels()
+    ops.stream.synchronize()
+    assert int(info.item()) == 0 and coupled == 8
+    chol = np.linalg.cholesky(a)
+    np.testing.assert_allclose(np.tril(host(minv)), np.linalg.inv(chol), atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_null_stream_caller_keeps_the_classic_chain(ops):
+    """On the legacy default stream the rows kernels would serialise with the CU-masked update stream: the library must not
+    couple there."""
+    n = 3072
+    a = spd(n, np.random.default_rng(3))
+    ad = dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
+    assert int(info.item()) == 0 and ops.last_coupled_panels() == 0

@@ -2,6 +2,8 @@ import sys, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops, make_spec
 ops = get_ops()
+if os.environ.get('PG_TORCH_SIDE_STREAM'):
+    _side = torch.cuda.Stream(); torch.cuda.set_stream(_side)   # everything below runs on a non-default stream
 for n in ([int(a) for a in sys.argv[1:]] or [8192, 16384]):
     d = 8
     rng = np.random.default_rng(1234)
