@@ -336,7 +336,7 @@ def main():
 
     legs = rank == 0 and world == 1 and not args.no_legs
     if legs:
-        # potrf alone and the covariance build, HIP events on torch's current stream (the library's stream)
+        # potrf alone and the covariance build, HIP events on torch's current stream (the library's caller stream)
         exp = model.gpl._device_data()[0]
         npad = exp.n_pad
         spec = make_spec([0], [0], [d + 1])
@@ -380,6 +380,7 @@ def main():
                     "frac_of_fp64_matrix_peak": nn ** 3 / 3.0 / t / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
 
         out["cholesky"] = chol_leg(n)
+        out["cholesky"]["coupled_panels"] = ops.last_coupled_panels()
         del a, invd
         # BASELINE config 2: single GP, N=8192 D=8 fp64 -- kernel build + Cholesky + alpha (fit), then mean + diag variance
         # at 8192 test points (predict; includes L^-1 on the first call)
@@ -396,7 +397,8 @@ def main():
             t2l = timed(lambda: ops.kernel_build(spec, hpd, x2d, None, a, lower_only=True, jitter=1e-7), 3)
             t2 = timed(fac2, 5) - t2l
             out["cholesky_n8192"] = {"n": 8192, "ms": t2, "tflops": 8192 ** 3 / 3.0 / t2 / 1e9,
-                                     "frac_of_fp64_matrix_peak": 8192 ** 3 / 3.0 / t2 / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
+                                     "frac_of_fp64_matrix_peak": 8192 ** 3 / 3.0 / t2 / 1e9 / FP64_MATRIX_PEAK_TFLOPS,
+                                     "coupled_panels": ops.last_coupled_panels()}
             del a, invd, x2d
         gp2 = pg.Exact_GP(torch.from_numpy(x2), torch.from_numpy(y2), cov, eager_inverse=True)   # variances follow
         gp2.set_params(torch.from_numpy(hp))

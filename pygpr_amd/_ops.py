@@ -3,7 +3,6 @@ produced by libpygpr_hip through the C ABI (include/pygpr_hip.h).  No CPU path e
 `get_ops()` raises when the library or a GPU is missing."""
 import atexit
 import ctypes as C
-import functools
 import os
 
 import torch
@@ -41,10 +40,6 @@ class HipOps:
         _lib.check(self.lib.pg_create(C.byref(h)), "pg_create")
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
-        # Every public entry point of the package runs on this stream (on_compute_stream below), never on the legacy default
-        # stream: the factorisation's flag-coupled chain uses the caller's stream as its second resident queue, which the null
-        # stream cannot be (it serialises with the library's CU-masked streams).  PG_NO_COMPUTE_STREAM=1 stays on the caller's.
-        self.stream = None if os.environ.get("PG_NO_COMPUTE_STREAM") else torch.cuda.Stream(device=self.device)
         # the library destroys live handles itself at process exit (capi.hip: C atexit registered by pg_create); closing
         # here as well releases the streams while torch's allocator is still up.  PG_NO_PY_ATEXIT=1 leaves it to the library
         # (used once to verify the library-side teardown under rocprofv3).
@@ -291,39 +286,6 @@ class HipOps:
 
 
 _OPS = None
-
-
-def _record(out, stream):
-    if isinstance(out, torch.Tensor):
-        if out.is_cuda:
-            out.record_stream(stream)
-    elif isinstance(out, (list, tuple)):
-        for o in out:
-            _record(o, stream)
-
-
-def on_compute_stream(fn):
-    """Decorator of the package's public device entry points: run on the process's compute stream (HipOps.stream), ordered
-    after the caller's current stream on entry and before it on exit; device tensors handed back are recorded on the caller's
-    stream for the caching allocator.  Nested calls and the CPU tier's test double (no `stream`) pass straight through."""
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        ops = get_ops()
-        side = getattr(ops, "stream", None)
-        if side is None:
-            return fn(*args, **kwargs)
-        cur = torch.cuda.current_stream()
-        if cur == side:
-            return fn(*args, **kwargs)
-        side.wait_stream(cur)
-        try:
-            with torch.cuda.stream(side):
-                out = fn(*args, **kwargs)
-        finally:
-            cur.wait_stream(side)
-        _record(out, cur)
-        return out
-    return wrapper
 
 
 def get_ops():

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._ops import get_ops, make_specs, pad_to, on_compute_stream
+from ._ops import get_ops, make_specs, pad_to
 
 
 class Covar(Protocol):
@@ -85,7 +85,6 @@ class _DeviceKernel:
                 raise RuntimeError("batch dimensions of hp / x / xp do not broadcast")
         return hb, xb, xpb, nb
 
-    @on_compute_stream
     def kernel(self, hp: Tensor, x: Tensor, xp: Tensor = None) -> Tensor:
         ops = get_ops()
         hb, xb, xpb, nb = self._batches(hp, x, xp)
@@ -112,7 +111,6 @@ class _DeviceKernel:
         res = torch.stack(outs) if nb > 1 else outs[0].contiguous()
         return res.to(x.device)
 
-    @on_compute_stream
     def kernel_and_grad(self, hp: Tensor, x: Tensor) -> List[Tensor]:
         ops = get_ops()
         hb, xb, _, nb = self._batches(hp, x)
@@ -146,7 +144,6 @@ class Squared_exponential(_DeviceKernel):
     def init_params(self, x: Tensor) -> Tensor:  # covar.py:96-100
         return torch.ones(self.get_params_shape(x), dtype=torch.float64)
 
-    @on_compute_stream
     def distance(self, x: Tensor, xp: Tensor = None) -> Tensor:
         """Squared Euclidean distances (covar.py:102-127): x [(b), n, d] -> [(b), n, n]; with xp [(b), m, d] the rows
         are the test points, [(b), m, n]; a batch of one is squeezed away like the reference does.  Evaluated on the
@@ -197,7 +194,6 @@ class White_noise(_DeviceKernel):
     def init_params(self, x: Tensor) -> Tensor:  # covar.py:221-225
         return 1e-4 * torch.ones(self.get_params_shape(x), dtype=torch.float64)
 
-    @on_compute_stream
     def kernel(self, hp: Tensor, x: Tensor, xp: Tensor = None) -> Tensor:
         if xp is not None:
             return torch.tensor(0)  # covar.py:243
@@ -219,7 +215,6 @@ class Compose(_DeviceKernel):
     def init_params(self, x: Tensor) -> Tensor:  # covar.py:45-48
         return torch.cat([c.init_params(x) for c in self.covars], dim=-1)
 
-    @on_compute_stream
     def kernel(self, hp: Tensor, x: Tensor, xp: Tensor = None) -> Tensor:
         if xp is not None and not layout(self, x.shape[-1])[0]:
             assert hp.shape[-1] == self._nhp(x.shape[-1])

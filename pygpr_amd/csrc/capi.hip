@@ -149,34 +149,30 @@ int pg_create(pg_handle* h) {
             c->lookahead = 0;
             (void)hipGetLastError();
         }
-        // background stream: a narrower partition, so that the chain and the trailing updates keep CUs of their own
-        const char* envb = getenv("PG_BG_CUS");
-        int bgcus = envb ? atoi(envb) : PG_BG_CUS;
-        if (bgcus < 8 || bgcus > ncu - reserved) bgcus = ncu - reserved;
-        for (int i = 0; i < 64; ++i) mask[i] = 0;
-        for (int cu = 0; cu < bgcus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
-        if (c->upd && hipExtStreamCreateWithCUMask(&c->bg, (uint32_t)words, mask) != hipSuccess) {
-            c->bg = nullptr;
-            (void)hipGetLastError();
+        // Streams are a budget: with a FIFTH hardware queue alive in the process (the caller's stream counts) the look-ahead loses
+        // its effect -- the chain's kernels then wait behind the update's tiles: 6.4 -> 10.4 ms at n = 8192 whichever stream is
+        // the extra one and whether or not it ever runs anything (stream count).  The handle therefore owns three: panel,
+        // rows, update.  The background stream of the fused factor-and-invert call (PG_BG_STREAM=1) is an experiment that needs the
+        // rows stream switched off (PG_ROWS_STREAM=0): its overlap returned 0.5 ms of 8.7 at n = 8192 and nothing at 16384.
+        c->bg = nullptr;
+        const char* envbg = getenv("PG_BG_STREAM");
+        if (envbg && atoi(envbg)) {
+            const char* envb = getenv("PG_BG_CUS");
+            int bgcus = envb ? atoi(envb) : PG_BG_CUS;
+            if (bgcus < 8 || bgcus > ncu - reserved) bgcus = ncu - reserved;
+            for (int i = 0; i < 64; ++i) mask[i] = 0;
+            for (int cu = 0; cu < bgcus; ++cu) mask[cu / 32] |= (1u << (cu % 32));
+            if (c->upd && hipExtStreamCreateWithCUMask(&c->bg, (uint32_t)words, mask) != hipSuccess) {
+                c->bg = nullptr;
+                (void)hipGetLastError();
+            }
         }
     }
-    {   // rows stream of the flag-coupled chain; PG_ROWS_KIND = none | plain | hi | mask (experiment)
-        const char* kind = getenv("PG_ROWS_KIND");
-        if (!kind) kind = "none";
-        hipError_t e = hipSuccess;
-        if (kind[0] == 'n') c->rows = nullptr;
-        else if (kind[0] == 'h') e = hipStreamCreateWithPriority(&c->rows, hipStreamNonBlocking, prio_hi);
-        else if (kind[0] == 'm') {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            PG_CHECK(hipGetDevice(&dev));
-            PG_CHECK(hipGetDeviceProperties(&prop, dev));
-            uint32_t mask[64];
-            for (int i = 0; i < 64; ++i) mask[i] = 0;
-            for (int cu = 0; cu < prop.multiProcessorCount && cu < 2048; ++cu) mask[cu / 32] |= (1u << (cu % 32));
-            e = hipExtStreamCreateWithCUMask(&c->rows, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask);
-        } else e = hipStreamCreateWithFlags(&c->rows, hipStreamNonBlocking);
-        if (e != hipSuccess) {
+    {   // rows stream of the flag-coupled chain (chainstep.hip): non-blocking, same priority as the panel stream
+        const char* envr = getenv("PG_ROWS_STREAM");
+        c->rows = nullptr;
+        if (!(envr && !atoi(envr)) && !c->bg && c->upd &&
+            hipStreamCreateWithPriority(&c->rows, hipStreamNonBlocking, prio_hi) != hipSuccess) {
             c->rows = nullptr;
             (void)hipGetLastError();
         }

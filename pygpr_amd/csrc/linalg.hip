@@ -489,14 +489,14 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // shorter than a leaf.
     // Measured (MI355X, fp64, build + factor): n = 4096 2.28 -> 1.77 ms, 8192 6.30 -> 5.37, 16384 30.75 -> 29.42 with the last 8192
     // rows coupled (2048: 30.41, 4096: 30.03, 6144: 29.62, 12288: 30.14, all: 31.48 -- while the trailing update still fills the
-    // chip the resident rows workgroups hold the slots it needs).  With the background inverse of the fused call running, the
-    // rows workgroups starve beside its long tiles: n = 16384 fused 51.5 -> 52.5 ms, so above 8192 the fused call keeps the classic
-    // chain (n = 8192 fused: 8.87 -> 8.16).
+    // chip the resident rows workgroups hold the slots it needs).  With the experimental background inverse of the fused call
+    // running (PG_BG_STREAM=1), the rows workgroups starve beside its long tiles: n = 16384 fused 51.5 -> 52.5 ms, so above 8192
+    // that configuration keeps the classic chain.
     static const int sync_env = getenv("PG_SYNC_ROWS") ? atoi(getenv("PG_SYNC_ROWS")) : -1;
-    const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && n > 8192) ? 0 : 8192);
-    // The rows stream is the CALLER's stream (idle while the factorisation runs on the handle's streams) -- a further stream of
-    // the handle's own costs the whole look-ahead 60 % (stream count) -- and it must be a real non-blocking stream: work
-    // on the null stream would wait for the CU-masked update stream, which can only be created blocking.
+    const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && ctx->bg && n > 8192) ? 0 : 8192);
+    // The rows stream is the handle's own (capi.hip).  Without one (PG_ROWS_STREAM=0) the caller's stream serves, if it is a
+    // real non-blocking stream: work on the null stream would wait for the CU-masked update stream, which can only be created
+    // blocking.
     hipStream_t rows_stream = ctx->rows;
     if (!rows_stream && st != nullptr && st != hipStreamLegacy && st != hipStreamPerThread) {
         unsigned int fl = 0;

@@ -18,7 +18,7 @@ from typing import Sequence
 import torch
 from torch import Tensor
 
-from ._ops import JITTER, get_ops, pad_to, on_compute_stream
+from ._ops import JITTER, get_ops, pad_to
 from .covar import Covar, layout, spec_of
 
 _CHUNK = 8192  # test points per device batch
@@ -173,7 +173,6 @@ class Exact_GP(GPR):
         return self.params.reshape(-1, nhp).to(torch.float64)
 
     # ---- the path ---------------------------------------------------------------------------
-    @on_compute_stream
     def update(self) -> None:
         if self.need_upd:
             ops = get_ops()
@@ -284,7 +283,6 @@ class Exact_GP(GPR):
             covs.append(cv)
         return means, covs
 
-    @on_compute_stream
     def predict(self, xp: Tensor, var: str = "full") -> Sequence[Tensor]:
         ops = get_ops()
         want = var if var in ("full", "diag") else "none"
@@ -311,7 +309,6 @@ class Exact_GP(GPR):
         return out.contiguous().to(self._x.device)
 
     @property
-    @on_compute_stream
     def krn(self) -> Tensor:
         """K + 1e-7 I as `Exact_GP.krn` holds it after update (gpr.py:67-68); rebuilt on access."""
         self.update()
@@ -325,7 +322,6 @@ class Exact_GP(GPR):
         return self._stack(outs)
 
     @property
-    @on_compute_stream
     def krnchd(self) -> Tensor:
         """Lower Cholesky factor with a zero upper triangle, like tc.cholesky (gpr.py:69)."""
         self.update()
@@ -338,7 +334,6 @@ class Exact_GP(GPR):
         return self._stack(outs)
 
     @property
-    @on_compute_stream
     def wt(self) -> Tensor:
         """alpha = K^-1 y (gpr.py:70-72): cholesky_solve(y[..., None], L) keeps y's leading dimensions."""
         self.update()

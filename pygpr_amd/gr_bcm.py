@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._ops import get_ops, pad_to, on_compute_stream
+from ._ops import get_ops, pad_to
 from .gpr import GPR, Exact_GP, _lin_alg_error
 from .loss import MLE, Loss
 
@@ -197,7 +197,6 @@ class GRBCM(GPR):
         ops.grbcm_finish_full(self._sums, mean_g, var_g, cov, mean)
         return mean, cov[:m, :m]
 
-    @on_compute_stream
     def aggregate(self, ys_g, covars_g, ys_l, covars_l, var="diag"):
         """GRBCM.aggregate (gr_bcm.py:116-149) on tensors shaped like Exact_GP.predict's outputs."""
         ops = get_ops()
@@ -217,7 +216,6 @@ class GRBCM(GPR):
         self.beta, self.prec = self.beta.to(ys_g.device), self.prec.to(ys_g.device)
         return mean.to(ys_g.device), out.to(ys_g.device)
 
-    @on_compute_stream
     def predict(self, xs, var="diag"):
         ops = get_ops()
         want = "diag" if var == "diag" else "full"
@@ -261,7 +259,6 @@ class GRBCM_MLE(Loss):
         if self._mle is not None:
             self._mle.memoize = bool(on)
 
-    @on_compute_stream
     def _reduce(self, vec):
         g = self.model
         if g.distributed:
@@ -274,7 +271,6 @@ class GRBCM_MLE(Loss):
                 vec = t.cpu().numpy()
         return vec
 
-    @on_compute_stream
     def _local(self, params, want_grad):
         """[sum_c NLML_c, gradient, status]: the status word rides in the same all-reduce, so that a non-PD expert on
         one rank raises LinAlgError on every rank instead of leaving the others blocked in the collective."""

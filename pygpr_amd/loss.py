@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from numpy import ndarray
 
-from ._ops import JITTER, get_ops, on_compute_stream
+from ._ops import JITTER, get_ops
 from .covar import layout, spec_of
 from .gpr import GPR, _lin_alg_error
 
@@ -68,7 +68,6 @@ class MLE(Loss):
             }
         return self._buf
 
-    @on_compute_stream
     def _evaluate(self, params: ndarray, want_grad: bool):
         """One evaluation, memoised on (parameters, data identity and version, covariance): the reference re-factorises on
         every call (loss.py:39,64,97); CG_Quad / BFGS_Quad / hessian ask for grad(par) at the same point again and again,

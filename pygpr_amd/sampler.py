@@ -9,7 +9,7 @@ differences instead of the reference's GEMM expansion (sampler.py:94-100).  `sam
 """
 import torch
 
-from ._ops import get_ops, on_compute_stream
+from ._ops import get_ops
 
 
 class UNIFORM(object):
@@ -32,7 +32,6 @@ def _device_pair(x, c):
     return ops, ops.to_device(x.reshape(-1, x.shape[-1]), dt), ops.to_device(c.reshape(-1, c.shape[-1]), dt)
 
 
-@on_compute_stream
 def euclidean_dist(x, y):
     """Squared Euclidean distances [n, m] (sampler.py:94-100)."""
     ops, xd, yd = _device_pair(x, y)
@@ -41,7 +40,6 @@ def euclidean_dist(x, y):
     return out.to(x.device)
 
 
-@on_compute_stream
 def nearest_centre(x, xc):
     """Index of the nearest centre for every point (the argmin of sampler.py:80-82,112-116), int64 on x's device."""
     ops, xd, cd = _device_pair(x, xc)

@@ -387,7 +387,7 @@ def test_potrf_outer_panel_widths(ops, panel, n):
             ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
             assert int(info.item()) == 0
             outs.append(np.tril(host(ad)))
-        assert np.array_equal(outs[0], outs[1])
+        np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-13)   # to rounding: the coupled chain sums in another order
         np.testing.assert_allclose(outs[0], chol, atol=1e-11)
         # fused inverse with this width
         ad = dev(a)
@@ -623,18 +623,15 @@ def test_grbcm_terms(ops):
 
 # ---- flag-coupled chain (chainstep.hip): resident leaf + rows kernels handing over through device flags ------------------------
 def _potrf_on_compute_stream(ops, a, dtype=torch.float64):
-    """pg_potrf with the caller on a real non-blocking stream (the package's compute stream), which is what lets the library use
-    that stream as the second queue of the coupled chain."""
-    assert ops.stream is not None
-    ops.stream.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(ops.stream):
-        ad = dev(a, dtype)
-        n = a.shape[0]
-        info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        invd = ops.potrf_workspace(n, dtype)
-        ops.potrf(ad, invd, info)
-        coupled = ops.last_coupled_panels()
-    ops.stream.synchronize()
+    """pg_potrf from the caller's current stream (the legacy default stream here: the rows kernels run on the handle's own
+    rows stream, so the caller's stream does not matter)."""
+    ad = dev(a, dtype)
+    n = a.shape[0]
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd = ops.potrf_workspace(n, dtype)
+    ops.potrf(ad, invd, info)
+    coupled = ops.last_coupled_panels()
+    torch.cuda.synchronize()
     return ad, invd, int(info.item()), coupled
 
 
@@ -702,30 +699,33 @@ def test_coupled_chain_fp32(ops):
 
 @pytest.mark.gpu
 def test_coupled_chain_fused_inverse(ops):
-    """pg_potrf_trtri at n = 4096 on the compute stream: coupled chain + the triangular inverse behind it."""
+    """pg_potrf_trtri at n = 4096: coupled chain + the triangular inverse behind it."""
     n = 4096
     rng = np.random.default_rng(13)
     a = spd(n, rng)
-    ops.stream.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(ops.stream):
-        ad = dev(a)
-        info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        minv = ops.zeros(n, n)
-        ops.potrf_trtri(ad, ops.potrf_workspace(n, torch.float64), info, minv)
-        coupled = ops.last_coupled_panels()
-    ops.stream.synchronize()
+    ad = dev(a)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    minv = ops.zeros(n, n)
+    ops.potrf_trtri(ad, ops.potrf_workspace(n, torch.float64), info, minv)
+    coupled = ops.last_coupled_panels()
+    torch.cuda.synchronize()
     assert int(info.item()) == 0 and coupled == 8
     chol = np.linalg.cholesky(a)
     np.testing.assert_allclose(np.tril(host(minv)), np.linalg.inv(chol), atol=1e-9)
 
 
 @pytest.mark.gpu
-def test_null_stream_caller_keeps_the_classic_chain(ops):
-    """On the legacy default stream the rows kernels would serialise with the CU-masked update stream: the library must not
-    couple there."""
+def test_coupled_chain_from_a_side_stream_caller(ops):
+    """The caller on a non-default torch stream: same schedule, the result is ordered on that stream."""
     n = 3072
     a = spd(n, np.random.default_rng(3))
-    ad = dev(a)
-    info = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
-    assert int(info.item()) == 0 and ops.last_coupled_panels() == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ad = dev(a)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
+        coupled = ops.last_coupled_panels()
+        lower = torch.tril(ad).cpu().numpy()          # on the side stream, behind the factorisation
+    assert int(info.item()) == 0 and coupled == 6
+    np.testing.assert_allclose(lower, np.linalg.cholesky(a), atol=1e-11)
