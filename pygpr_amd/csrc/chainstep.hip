@@ -6,7 +6,7 @@
 // their inputs exist and hand over through flags in device memory (agent-scope, cdna_hip_programming.md guideline 16):
 //
 //   leaf stream : leaf(k)   waits diag[k] == NCRIT, factors tile (k, k), stores L_kk and inv_k, releases done[k]
-//   rows stream : rows(k)   one workgroup per 32 / 64 rows below tile (k, k):
+//   rows stream : rows(k)   one workgroup per 16 (block row k+1) / 32 rows below tile (k, k):
 //                   before done[k]:  acc = X[rows, o0:k0] X[blk k+1, o0:k0]^T      (the next block column's update by the panel's
 //                                    earlier columns: everything it reads is final since rows(k-1) ended)
 //                   after  done[k]:  X[rows, blk k] = A[rows, blk k] inv_k^T        (T)
@@ -68,23 +68,43 @@ template <> __device__ __forceinline__ void st_wt<float>(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), RLX_AGENT);
 }
 
-// acc[MI][2] += Aop[ROWS x K] B[128 x K]^T for this wave's 16 MI x 32 tile (waves: 2 row groups x 4 column groups).
+template <typename T> __device__ __forceinline__ T ld_wt(const T* p);   // load past this CU's L1 (sc1)
+template <> __device__ __forceinline__ double ld_wt<double>(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), RLX_AGENT));
+}
+template <> __device__ __forceinline__ float ld_wt<float>(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), RLX_AGENT));
+}
+
+// Whole workgroup: wait for *flag >= want WITHOUT an acquire: for workgroups whose every later load of handed-off bytes is ld_wt
+__device__ __forceinline__ void cs_wg_wait_wt(int* flag, int want, int* tmo, int* info) {
+    if (threadIdx.x == 0) {
+        if (!cs_spin_ge(flag, want, tmo)) atomicCAS(info, 0, -1);
+    }
+    __syncthreads();
+}
+
+// acc[NJ] += Aop[ROWS x K] B[128 x K]^T for this wave's 16 x 16 NJ tile.  RG = 2: 32 rows, waves as 2 row groups x 4 column
+// groups of 32 columns (NJ = 2);  RG = 1: 16 rows, 8 column groups of 16 columns (NJ = 1).
 //   A_LDS false: A rows from global (Ag, lda), staged;  true: A = the workgroup's LDS tile Xl[ROWS][CS_XLD], columns 0 .. K-1
 //   B from global (Bg, ldb), staged in K chunks of 32 with the next chunk's loads in flight during the MFMAs.
 //   lower_b: B[n][k] = 0 for k > n (the leaf's inverse): chunks past the wave's last column are skipped.
-template <typename T, int MI, bool A_LDS>
-__device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[MI][2], const T* __restrict__ Ag, long lda, const T* Xl,
+template <typename T, int RG, bool A_LDS>
+__device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[RG], const T* __restrict__ Ag, long lda, const T* Xl,
                                       const T* __restrict__ Bg, long ldb, int K, bool lower_b, T* As, T* Bs) {
-    constexpr int ROWS = 32 * MI;
+    constexpr int ROWS = 16 * RG, NJ = RG, WC = 16 * NJ;      // rows of the workgroup, column tiles and columns per wave
     constexpr int VE = 16 / sizeof(T);
     constexpr int VPR = CS_KC / VE;                              // 16-byte vectors per row of a chunk
     constexpr int NVB = NB * VPR, NVA = ROWS * VPR;
     constexpr int UB = (NVB + CS_NTH - 1) / CS_NTH, UA = (NVA + CS_NTH - 1) / CS_NTH;
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = wave >> 2, cg = wave & 3, fr = lane & 15, fk = lane >> 4;
-    vec_t vb[UB], va[UA];
-    auto issue = [&](int kc) {
+    const int rg = RG == 2 ? wave >> 2 : 0, cg = RG == 2 ? wave & 3 : wave, fr = lane & 15, fk = lane >> 4;
+    // TWO chunks in flight (two named register sets, the loop unrolled by two): with one, a chunk's loads are issued when the
+    // previous chunk starts its 0.2-0.4 us of MFMAs and the loop runs at one load latency per chunk -- 48 us for the 896-deep
+    // window of a 512-column panel's last step, longer than the leaf it is meant to hide behind.  K is a multiple of 128.
+    vec_t vb0[UB], va0[UA], vb1[UB], va1[UA];
+    auto issue = [&](vec_t (&vb)[UB], vec_t (&va)[UA], int kc) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int v = tid + u * CS_NTH;
@@ -98,9 +118,7 @@ __device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[MI][2], con
             }
         }
     };
-    if (K > 0) issue(0);
-    for (int kc = 0; kc < K; kc += CS_KC) {
-        __syncthreads();                                          // the previous chunk's readers are done
+    auto stage = [&](vec_t (&vb)[UB], vec_t (&va)[UA]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int v = tid + u * CS_NTH;
@@ -121,50 +139,107 @@ __device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[MI][2], con
                 }
             }
         }
-        __syncthreads();
-        if (kc + CS_KC < K) issue(kc + CS_KC);
-        if (lower_b && kc > 32 * cg + 31) continue;               // wave-uniform; the barriers above are still reached
+    };
+    auto compute = [&](int kc) {
+        if (lower_b && kc > WC * cg + WC - 1) return;             // wave-uniform; the barriers are outside
 #pragma unroll
         for (int ks = 0; ks < CS_KC / 4; ++ks) {
-            T a[MI], b[2];
+            T b[NJ];
+            const T a = A_LDS ? Xl[(16 * rg + fr) * CS_XLD + kc + 4 * ks + fk] : As[(16 * rg + fr) * CS_CLD + 4 * ks + fk];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = A_LDS ? Xl[(16 * MI * rg + 16 * i + fr) * CS_XLD + kc + 4 * ks + fk]
-                             : As[(16 * MI * rg + 16 * i + fr) * CS_CLD + 4 * ks + fk];
+            for (int j = 0; j < NJ; ++j) b[j] = Bs[(WC * cg + 16 * j + fr) * CS_CLD + 4 * ks + fk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(32 * cg + 16 * j + fr) * CS_CLD + 4 * ks + fk];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[j] = Mfma<T>::run(a, b[j], acc[j]);
         }
+    };
+    if (K > 0) {
+        issue(vb0, va0, 0);
+        issue(vb1, va1, CS_KC);
+    }
+    for (int kc = 0; kc < K; kc += 2 * CS_KC) {
+        __syncthreads();                                          // the previous chunk's readers are done
+        stage(vb0, va0);
+        __syncthreads();
+        if (kc + 2 * CS_KC < K) issue(vb0, va0, kc + 2 * CS_KC);
+        compute(kc);
+        __syncthreads();
+        stage(vb1, va1);
+        __syncthreads();
+        if (kc + 3 * CS_KC < K) issue(vb1, va1, kc + 3 * CS_KC);
+        compute(kc + CS_KC);
     }
 }
 
-template <typename T, int MI>
+// The K = 128 stages of the workgroups the next leaf waits for (16 rows, one 16 x 16 tile per wave): with 8 MFMAs per wave and
+// chunk the staged loop above is a chain of load latencies (a chunk's loads are issued when the previous chunk starts computing:
+// 0.2 us of MFMA against 1.5-2 us of latency, four times over).  Here ALL of B (128 x 128) is in flight at once, 16 vectors per
+// thread, L1-bypassing (published by another resident kernel, no acquire in front), and goes through LDS chunk by chunk as it
+// lands.  lower_b: B[n][k] = 0 for k > n.
+template <typename T>
+__device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T* Xl, const T* __restrict__ Bg, long ldb, bool lower_b,
+                                           T* Bs) {
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int VPR = CS_KC / VE, NVB = NB * VPR, UB = (NVB + CS_NTH - 1) / CS_NTH, NCH = NB / CS_KC;
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, (int)((127 * ldb + NB) * sizeof(T)), 0x00020000);
+    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    vec_t vb[NCH][UB];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int v = tid + u * CS_NTH, row = v / VPR;
+            // a lower-triangular B has nothing in chunk c for the rows above it
+            if (v < NVB && !(lower_b && row + 1 <= c * CS_KC))
+                vb[c][u] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rB, (int)(((long)row * ldb + c * CS_KC + (v % VPR) * VE) * sizeof(T)), 0, 16));
+            else
+#pragma unroll
+                for (int e = 0; e < VE; ++e) vb[c][u][e] = (T)0;
+        }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int v = tid + u * CS_NTH;
+            if (v < NVB) {
+                T* d = Bs + (v / VPR) * CS_CLD + (v % VPR) * VE;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) d[e] = vb[c][u][e];
+            }
+        }
+        __syncthreads();
+        if (lower_b && c * CS_KC > 16 * cg + 15) continue;        // wave-uniform
+#pragma unroll
+        for (int ks = 0; ks < CS_KC / 4; ++ks)
+            acc = Mfma<T>::run(Xl[fr * CS_XLD + c * CS_KC + 4 * ks + fk], Bs[(16 * cg + fr) * CS_CLD + 4 * ks + fk], acc);
+    }
+}
+
+template <typename T, int RG>
 __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, long lda, int row0, int o0, int k0, bool has_next,
                                              bool crit, const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next, int ncrit,
-                                             int* tmo, int* info) {
-    constexpr int ROWS = 32 * MI;
+                                             int* tmo, int* info, int direct, long long* tlog) {
+    constexpr int ROWS = 16 * RG, NJ = RG, WC = 16 * NJ;
+#define TL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     constexpr int VE = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     T* Xl = reinterpret_cast<T*>(smem_raw);                      // [ROWS][CS_XLD]
     T* As = Xl + ROWS * CS_XLD;                                  // [ROWS][CS_CLD]
     T* Bs = As + ROWS * CS_CLD;                                  // [128][CS_CLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = wave >> 2, cg = wave & 3, fr = lane & 15;
+    const int rg = RG == 2 ? wave >> 2 : 0, cg = RG == 2 ? wave & 3 : wave, fr = lane & 15;
     T* Arow = A + (long)row0 * lda;                              // this workgroup's rows
     const T* Brow = A + (long)(k0 + NB) * lda;                   // block row k+1
-    typename Mfma<T>::acc_t acc[MI][2], cin[MI][2];
+    typename Mfma<T>::acc_t acc[NJ], cin[NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[i][j][r] = (T)0;
-                cin[i][j][r] = (T)0;
-            }
+        for (int r = 0; r < 4; ++r) {
+            acc[j][r] = (T)0;
+            cin[j][r] = (T)0;
+        }
     // this workgroup's block of column k -> LDS (its values are final except for the solve), and the block of column k+1
     for (int v = tid; v < ROWS * NB / VE; v += CS_NTH) {
         const int r = v / (NB / VE), c = (v % (NB / VE)) * VE;
@@ -174,67 +249,84 @@ __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, 
     }
     if (has_next) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    cin[i][j][r] = Arow[(long)(16 * MI * rg + 16 * i + Mfma<T>::row(lane, r)) * lda + k0 + NB + 32 * cg + 16 * j + fr];
+            for (int r = 0; r < 4; ++r)
+                cin[j][r] = Arow[(long)(16 * rg + Mfma<T>::row(lane, r)) * lda + k0 + NB + WC * cg + 16 * j + fr];
         // the panel's earlier columns
-        cs_mm<T, MI, false>(acc, Arow + o0, lda, Xl, Brow + o0, lda, k0 - o0, false, As, Bs);
+        cs_mm<T, RG, false>(acc, Arow + o0, lda, Xl, Brow + o0, lda, k0 - o0, false, As, Bs);
     }
-    cs_wg_wait(done_k, 1, tmo, info);
     // T: rows x inv_k^T
-    typename Mfma<T>::acc_t t[MI][2];
+    typename Mfma<T>::acc_t t[NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[i][j][r] = (T)0;
-    cs_mm<T, MI, true>(t, nullptr, 0, Xl, inv, NB, NB, true, As, Bs);
+        for (int r = 0; r < 4; ++r) t[j][r] = (T)0;
+    TL(4);
+    if (RG == 1 && direct) {
+        cs_wg_wait_wt(done_k, 1, tmo, info);
+        TL(5);
+        cs_mm_k128<T>(t[0], Xl, inv, NB, true, Bs);
+    } else {
+        cs_wg_wait(done_k, 1, tmo, info);
+        cs_mm<T, RG, true>(t, nullptr, 0, Xl, inv, NB, NB, true, As, Bs);
+    }
+    TL(6);
     __syncthreads();                                             // every wave has read its rows of Xl
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * MI * rg + 16 * i + Mfma<T>::row(lane, r), cc = 32 * cg + 16 * j + fr;
-                Xl[rr * CS_XLD + cc] = t[i][j][r];
-                T* g = Arow + (long)rr * lda + k0 + cc;
-                if (crit) st_wt<T>(g, t[i][j][r]);
-                else *g = t[i][j][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * rg + Mfma<T>::row(lane, r), cc = WC * cg + 16 * j + fr;
+            Xl[rr * CS_XLD + cc] = t[j][r];
+            T* g = Arow + (long)rr * lda + k0 + cc;
+            if (crit) st_wt<T>(g, t[j][r]);
+            else *g = t[j][r];
+        }
     if (crit) cs_wg_signal(brow_k);
+    TL(7);
     if (!has_next) return;
-    cs_wg_wait(brow_k, ncrit, tmo, info);                        // also orders this workgroup's Xl stores before the loads below
-    cs_mm<T, MI, true>(acc, nullptr, 0, Xl, Brow + k0, lda, NB, false, As, Bs);
+    if (RG == 1 && direct) {                                     // (the barrier inside also orders the Xl stores above)
+        cs_wg_wait_wt(brow_k, ncrit, tmo, info);
+        TL(8);
+        cs_mm_k128<T>(acc[0], Xl, Brow + k0, lda, false, Bs);
+    } else {
+        cs_wg_wait(brow_k, ncrit, tmo, info);
+        cs_mm<T, RG, true>(acc, nullptr, 0, Xl, Brow + k0, lda, NB, false, As, Bs);
+    }
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                T* g = Arow + (long)(16 * MI * rg + 16 * i + Mfma<T>::row(lane, r)) * lda + k0 + NB + 32 * cg + 16 * j + fr;
-                const T v = cin[i][j][r] - acc[i][j][r];
-                if (crit) st_wt<T>(g, v);
-                else *g = v;
-            }
+        for (int r = 0; r < 4; ++r) {
+            T* g = Arow + (long)(16 * rg + Mfma<T>::row(lane, r)) * lda + k0 + NB + WC * cg + 16 * j + fr;
+            const T v = cin[j][r] - acc[j][r];
+            if (crit) st_wt<T>(g, v);
+            else *g = v;
+        }
+    TL(9);
     if (crit) cs_wg_signal(diag_next);
+    TL(10);
+#undef TL
 }
 
-// grid = m / 32 workgroups (m = rows below tile (k, k)), 32 rows each; the first four own block row k+1 (what the next leaf waits
-// for).  77 KB of LDS and at most 128 VGPRs: a workgroup fits beside one resident 128 x 128 GEMM block of the trailing update.
+// grid = 8 + (m - 128) / 32 workgroups (m = rows below tile (k, k)): the first eight own 16 rows each of block row k+1 -- what
+// the next leaf waits for: half the rows, half the MFMA time on the critical path -- the others 32 rows each.  At most 77 KB of
+// LDS and 128 VGPRs: a workgroup fits beside one resident 128 x 128 GEMM block of the trailing update.
 // (64-row workgroups for the rows further down halve the re-reads of block row k+1 but need 119 KB: they would only ever start
 // on an empty CU.)
+#define CS_NCRIT 8
 template <typename T>
 __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
                                                                const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
-                                                               int* tmo, int* info) {
+                                                               int* tmo, int* info, int direct, long long* tlog) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int w = blockIdx.x;
-    cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 32 * w, o0, k0, has_next != 0, w < 4, inv, done_k, brow_k, diag_next, 4, tmo, info);
+    if (w < CS_NCRIT)
+        cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 16 * w, o0, k0, has_next != 0, true, inv, done_k, brow_k, diag_next, CS_NCRIT,
+                           tmo, info, direct, w == 0 ? tlog : nullptr);
+    else
+        cs_rows_body<T, 2>(smem_raw, A, lda, k0 + 2 * NB + 32 * (w - CS_NCRIT), o0, k0, has_next != 0, false, inv, done_k, brow_k,
+                           diag_next, CS_NCRIT, tmo, info, direct, nullptr);
 }
 
 __global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(flag, value, RLX_AGENT); }
@@ -251,8 +343,10 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(m / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
-                       brow_k, diag_next, tmo, info);
+    static const int direct = getenv("PG_CS_K128") ? atoi(getenv("PG_CS_K128")) : 1;
+    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
+                       brow_k, diag_next, tmo, info, direct,
+                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (k0 / NB) : nullptr);
     PG_CHECK(hipGetLastError());
     return 0;
 }

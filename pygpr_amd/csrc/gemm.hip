@@ -242,21 +242,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
     }
 }
 
-// LDS request floor of the next launches (pg_gemm sets it): 84 KB leaves room for ONE workgroup of the launch per CU, so half of
-// every CU's registers and LDS stays free for the kernels of another stream
-static thread_local size_t g_lds_floor = 0;
-#define HALF_CU_LDS (84 * 1024)
-
 template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
 static int launch(hipStream_t st, const GemmP<T>& p) {
     typedef Stage<T, BM, !TA, BKT, 64 * NW> SA;
     typedef Stage<T, BN, TB, BKT, 64 * NW> SB;
-    const size_t lds = std::max<size_t>(2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T), g_lds_floor);
+    const size_t lds = 2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T);
     static bool attr_done = false;
     auto kern = pg_gemm_kernel<T, TA, TB, BM, BN, EPI, BKT, NW>;
     if (!attr_done) {
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)std::max<size_t>(2 * (SA::LDS_ELEMS + SB::LDS_ELEMS) * sizeof(T), HALF_CU_LDS)));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     if (p.M % BM || p.N % BN || p.K % BKT || (p.tri && BM != BN)) {
@@ -303,9 +298,6 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     const bool w4 = w4env || sizeof(T) == 4 || (variant == GEMM_NN_128_SS && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
-    static const int bg_half = getenv("PG_BG_HALF") ? atoi(getenv("PG_BG_HALF")) : 0;
-    static const int upd_half = getenv("PG_UPD_HALF") ? atoi(getenv("PG_UPD_HALF")) : 0;
-    g_lds_floor = (ctx && ((bg_half && st == ctx->bg) || (upd_half && st == ctx->upd))) ? HALF_CU_LDS : 0;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;

@@ -30,6 +30,31 @@
 #endif
 #define NWV (NTH / 64)
 
+// 16-byte (two doubles) / 8-byte (two floats) accesses that bypass this CU's L1 and write through the XCD's L2 (sc1): what a
+// kernel uses for bytes another resident kernel hands it, or takes from it, without a fence (chainstep.hip; guideline 16).
+typedef int pg_v4i __attribute__((ext_vector_type(4)));
+typedef double pg_pair_d __attribute__((ext_vector_type(2)));
+typedef float pg_pair_f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pg_pair_d ld_pair_wt(const double* base, __amdgpu_buffer_rsrc_t r, long elem_off) {
+    (void)base;
+    return __builtin_bit_cast(pg_pair_d, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem_off * 8), 0, 16));
+}
+__device__ __forceinline__ void st_pair_wt(double* base, __amdgpu_buffer_rsrc_t r, long elem_off, pg_pair_d v) {
+    (void)base;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pg_v4i, v), r, (int)(elem_off * 8), 0, 16);
+}
+__device__ __forceinline__ pg_pair_f ld_pair_wt(const float* base, __amdgpu_buffer_rsrc_t r, long elem_off) {
+    (void)r;
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + elem_off), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(pg_pair_f, u);
+}
+__device__ __forceinline__ void st_pair_wt(float* base, __amdgpu_buffer_rsrc_t r, long elem_off, pg_pair_f v) {
+    (void)r;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(base + elem_off), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T> __device__ __forceinline__ T bcast_lane(T v, int src);
 template <> __device__ __forceinline__ double bcast_lane<double>(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -328,9 +353,11 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
 // between "A" and "B", no branches (a bad pivot is recorded with a compare/select and acted on after the 16 columns).
 // Waves 4-11 meanwhile run the deferred trailing update of the previous micro-panel and the inverse's block row, as before.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool WT>   // WT: tile and inverse move with write-through / L1-bypassing accesses (the coupled chain)
 __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                            int* __restrict__ info, int col0, int ablate) {
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((127 * lda + 128) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(inv, 0, inv ? (int)((127 * ldi + 128) * sizeof(T)) : 0, 0x00020000);
     T* S = reinterpret_cast<T*>(smem_raw);
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
     int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
@@ -347,7 +374,10 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
         for (int u = 0; u < NLD; ++u) {
             const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
             v[u] = pair_t{(T)0, (T)0};
-            if (idx < NB * NB / 2 && k <= i) v[u] = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
+            if (idx < NB * NB / 2 && k <= i) {
+                if (WT) v[u] = ld_pair_wt(A, rA, (long)i * lda + k);
+                else v[u] = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
+            }
         }
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
@@ -447,7 +477,8 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
         pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
         if (k > i) v[0] = (T)0;
         if (k + 1 > i) v[1] = (T)0;
-        *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+        if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+        else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
     }
     if (!want_inv) return;
     auto store_inv_rows = [&](int row_lo, int row_hi) {
@@ -464,7 +495,8 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
                 v[0] = Xt[0];
                 v[1] = Xt[1];
             }
-            *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+            if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
+            else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
         }
     };
     store_inv_rows(0, 112);
@@ -478,17 +510,19 @@ template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                                        int* __restrict__ info, int col0, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf2_body<T>(smem_raw, A, lda, inv, ldi, info, col0, ablate);
+    leaf2_body<T, false>(smem_raw, A, lda, inv, ldi, info, col0, ablate);
 }
 
 // The leaf of the flag-coupled chain (chainstep.hip): resident before its tile exists.  Waits until the `want` workgroups that
-// own the tile have published it (*ready, write-through stores on their side), factors, then releases *done: plain stores, every
-// wave drained, one agent-scope release (this CU's XCD is reserved for the chain: its L2 holds little else that is dirty).
+// own the tile have published it (*ready; they store it write-through), loads it past this CU's L1, factors, stores L and the
+// inverse write-through, drains, and sets *done: no fence on either side (every handed-off byte is an sc1 store read by sc1
+// loads, or read behind the reader's own acquire).
 // *done is set on every path (bad pivot, earlier failure, timeout): the rows below wait for it.
-template <typename T>
+template <typename T, bool WT>
 __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
-                                                        int col0, int* ready, int want, int* done, int* tmo) {
+                                                        int col0, int* ready, int want, int* done, int* tmo, long long* tlog) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
         for (unsigned it = 0;; ++it) {
             if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
@@ -500,16 +534,23 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
-    leaf2_body<T>(smem_raw, A, lda, inv, NB, info, col0, 0);
+    if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
+    leaf2_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, 0);
+    if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tlog && threadIdx.x == 0) tlog[3] = wall_clock64();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -519,11 +560,17 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     if (!attr_done) {
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T>),
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(pg_leaf2s_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo);
+    static const int wt = getenv("PG_CS_LEAF_WT") ? atoi(getenv("PG_CS_LEAF_WT")) : 1;
+    if (wt) hipLaunchKernelGGL((pg_leaf2s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (col0 / NB) : nullptr);
+    else hipLaunchKernelGGL((pg_leaf2s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (col0 / NB) : nullptr);
     PG_CHECK(hipGetLastError());
     return 0;
 }

@@ -505,7 +505,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     }
     const bool want_cp = ctx->lookahead && !ctx->prof_on && rows_stream && sync_rows > 0 && ctx->panel_mode == 0;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
-    for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, 512) : NBO) pb.push_back(c);
+    static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 512;
+    for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, cs_panel) : NBO) pb.push_back(c);
     pb.push_back(n);
     const int npan = (int)pb.size() - 1;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
@@ -547,7 +548,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             hipStream_t rs = rows_stream;
             if (o == o_s) {
                 // everything so far that touched these columns ran on the panel stream or was waited for there
-                if ((rc = pg_flagset(ps, f_diag + o0 / NB, 4))) return rc;
+                if ((rc = pg_flagset(ps, f_diag + o0 / NB, PG_CS_NCRIT))) return rc;
                 if ((rc = pool_event(ctx, 4 + 2 * npan, &ev))) return rc;
                 PG_CHECK(hipEventRecord(ev, ps));
                 PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
@@ -555,7 +556,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             for (int k0 = o0; k0 < oend; k0 += NB) {
                 const int kb = k0 / NB;
                 T* inv = invD + (long)kb * NB * NB;
-                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, 4, f_done + kb, f_tmo))) return rc;
+                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, f_tmo))) return rc;
                 if (n - k0 - NB <= 0) break;
                 const int c = k0 + NB;                       // the block column this step brings up to date
                 const int oc = c < oend ? o : o + 1;         // its panel
@@ -568,8 +569,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     return rc;
             }
         }
-        static const int mode1_rows = getenv("PG_MODE1_ROWS") ? atoi(getenv("PG_MODE1_ROWS")) : 0;
-        const int mode = (oend < n && n - o0 > mode1_rows) ? ctx->panel_mode : 0;
+        const int mode = (oend < n) ? ctx->panel_mode : 0;
         const bool v2 = mode == 1;
         const int tri_end = v2 ? oend : n;     // last row the panel stream's 128-column steps touch
         for (int k0 = o0; k0 < oend && !cp; k0 += NB) {

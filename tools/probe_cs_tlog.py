@@ -1,0 +1,35 @@
+"""Timestamps inside the flag-coupled chain (PG_CS_TLOG=1): per 128-column step, from the leaf and the first rows workgroup.
+python tools/probe_cs_tlog.py [n]   (n <= 8192 so that every panel is coupled)"""
+import os, sys
+os.environ["PG_CS_TLOG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pygpr_amd._ops import get_ops, make_spec
+ops = get_ops()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+d = 8
+rng = np.random.default_rng(1234)
+x = torch.from_numpy(rng.random((n, d))).cuda()
+hp = torch.tensor([1.0] + [1.0] * d + [0.1], dtype=torch.float64).cuda()
+spec = make_spec([0], [0], [d + 1])
+kl = ops.empty(n, n)
+invd = ops.potrf_workspace(n, torch.float64); info = torch.zeros(1, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    invd.zero_()
+    ops.kernel_build(spec, hp, x, None, kl, lower_only=True, jitter=1e-7); ops.potrf(kl, invd, info)
+    torch.cuda.synchronize()
+nblk = n // 128
+w = min(n, 2048)
+base = n * 128 + w * w                      # doubles: start of the flag words
+tmo_off_bytes = base * 8 + 3 * nblk * 4
+tl = invd.view(torch.int64)[(tmo_off_bytes // 8) + 512: (tmo_off_bytes // 8) + 512 + 16 * nblk].cpu().numpy().reshape(nblk, 16)
+# wall_clock64: 100 MHz
+t0 = tl[0, 0]
+us = lambda v: (v - t0) / 100.0
+print("step | leaf: start flag-seen body-end drained | rows wg0: before-wait flag-seen T-done published brow-seen U-done published  (us; deltas)")
+for k in range(1, min(nblk - 1, 14)):
+    L = tl[k]; Lp = tl[k - 1]
+    print("%3d leaf start %8.1f | wait %5.1f body %5.1f drain %4.1f || rows: done-flag seen +%4.1f after leaf drained; T %4.1f; publish %4.1f; brow wait %4.1f; U %4.1f; publish %4.1f | next leaf sees tile +%4.1f" % (
+        k, us(L[0]), (L[1] - L[0]) / 100, (L[2] - L[1]) / 100, (L[3] - L[2]) / 100,
+        (L[5] - L[3]) / 100, (L[6] - L[5]) / 100, (L[7] - L[6]) / 100, (L[8] - L[7]) / 100, (L[9] - L[8]) / 100, (L[10] - L[9]) / 100,
+        (tl[k + 1][1] - L[10]) / 100))
