@@ -248,11 +248,11 @@ __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ M, lo
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ L, long ldl, int n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ L, long ldl, int n, double* __restrict__ out, double scale) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int i = tid; i < n; i += 256) s += 2.0 * log((double)L[(long)i * ldl + i]);
+    double s = 0.0;                 // scale = 2 on the factor's diagonal, -2 on its inverse's (log det K = 2 sum log L_ii)
+    for (int i = tid; i < n; i += 256) s += scale * log((double)L[(long)i * ldl + i]);
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
@@ -757,7 +757,7 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
 }
 
 template <typename T> int pg_logdet_t(hipStream_t st, int n, const T* L, long ldl, double* out) {
-    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, n, out);
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, n, out, 2.0);
     LAUNCH_CHECK();
     return 0;
 }
@@ -770,19 +770,22 @@ int pg_nlml_value_t(hipStream_t st, int n, const T* L, long ldl, const T* y, con
 }
 
 // alpha = Minv^T (Minv y) and the NLML, on the handle's side stream: the two triangular mat-vecs are HBM-bound (2 x 8 n^2 / 2 B)
-// and overlap with the MFMA-bound L^-T L^-1 the caller enqueues next.  The log-determinant is taken on the caller's stream
-// first (K^-1 is about to overwrite the factor).  ctx->side_pending makes the next entry point that may read alpha / out wait.
+// and overlap with the MFMA-bound L^-T L^-1 the caller enqueues next.  The log-determinant rides along, from the diagonal of
+// L^-1 (K^-1 is about to overwrite the factor).  ctx->side_pending makes the next entry point that may read alpha / out wait.
 template <typename T>
 int pg_alpha_nlml_async_t(pg_ctx* ctx, hipStream_t st, int n_real, int n, const T* L, long ldl, const T* Minv, long ldm, const T* y,
                           T* u, T* alpha, T* work, double* out) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_alpha_nlml_async: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
-    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, L, ldl, n_real, out + 1);
-    LAUNCH_CHECK();
     hipStream_t side = (ctx->lookahead && !ctx->prof_on) ? ctx->aux : st;
     if (side != st) {
         PG_CHECK(hipEventRecord(ctx->ev[4], st));
         PG_CHECK(hipStreamWaitEvent(side, ctx->ev[4], 0));
     }
+    // the log-determinant from the inverse's diagonal (1 / L_ii): the factor's buffer may be overwritten by the caller's next
+    // call (K^-1 goes there), the inverse's is only read
+    (void)L; (void)ldl;
+    hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, side, Minv, ldm, n_real, out + 1, -2.0);
+    LAUNCH_CHECK();
     int rc;
     if ((rc = pg_trmv_t<T>(ctx, side, n, Minv, ldm, 0, y, u, work))) return rc;
     if ((rc = pg_trmv_t<T>(ctx, side, n, Minv, ldm, 1, u, alpha, work))) return rc;

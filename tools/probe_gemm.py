@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygpr_amd._ops import get_ops
 from pygpr_amd._lib import GEMM_NT, GEMM_TN
 ops = get_ops()
