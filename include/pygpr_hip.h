@@ -51,8 +51,10 @@ typedef struct pg_covspec {
 
 int pg_version(void);
 const char* pg_last_error(void);
-/* A handle owns three HIP streams (panel / update / background) and a pool of events.  Release it with pg_destroy when
- * done; handles still alive at process exit are destroyed by the library itself (a C atexit handler registered by the
+/* A handle owns three HIP streams (panel / rows / update) and a pool of events.  Streams are a budget on MI355X / ROCm 7.2: with
+ * a fifth hardware queue alive in the process (the caller's counts) the factorisation's look-ahead loses 20-60 %, so keep your own
+ * GPU work on ONE stream -- any stream, the legacy default one included ("the stream budget").  Release the handle with
+ * pg_destroy when done; handles still alive at process exit are destroyed by the library itself (a C atexit handler registered by the
  * first pg_create, so it runs before the HIP runtime's own teardown).  pg_destroy on an already released handle is a no-op. */
 int pg_create(pg_handle* h);
 int pg_destroy(pg_handle h);
@@ -75,14 +77,15 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
 /* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag is the factorisation's
  * workspace of pg_potrf_worksize(dtype, n) elements: its first n * 128 elements receive the inverses of the 128x128
  * diagonal blocks ([n/128][128][128]) that drive every later solve (pg_potrs_vec, pg_trtri ... only read that part);
- * the rest is scratch of the panel step (inverse of the current panel's triangular factor, the panel's solved rows). */
+ * the rest is scratch of the call: the flag words through which the resident kernels of the coupled chain hand over
+ * (csrc/chainstep.hip; zeroed by every call) and the buffers of the optional recursive panel step.
+ * info: 0, or j + 1 when the leading minor of order j + 1 is not positive definite (LAPACK's convention), or -1 if a bounded wait
+ * inside the coupled chain expired (never seen; the factor is then undefined). */
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
 
 /* pg_potrf followed by pg_trtri in one call: Minv = L^-1 as well (tc.cholesky + the triangular half of the
- * cholesky_solve calls of loss.py:97,116).  The inverse of the leading half of L and the product L21 Minv11 of the
- * top level only need columns that are final half-way through the factorisation; they run on a background stream
- * while the chain-bound tail of the Cholesky leaves most of the chip idle. */
+ * cholesky_solve calls of loss.py:97,116). */
 int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
                    void* stream);
 
@@ -119,8 +122,8 @@ int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const 
                   double* out, void* stream);
 
 /* The same alpha and NLML as pg_trmv x 2 + pg_nlml_value (alpha = Minv^T (Minv y), loss.py:102-109), arranged to overlap with the
- * caller's next launch: the log-determinant is read from L on `stream` (K^-1 may overwrite L next), then the two HBM-bound
- * triangular mat-vecs and the value run on the handle's side stream beside the MFMA-bound pg_lauum the caller enqueues next.
+ * caller's next launch: the log-determinant (from the diagonal of Minv: K^-1 may overwrite L next), the two HBM-bound triangular
+ * mat-vecs and the value run on the handle's side stream beside the MFMA-bound pg_lauum the caller enqueues next.
  * out[0] receives the NLML (out[1] is scratch: log det K); u, alpha: n elements; work: (n/256) n elements.  Any later entry point
  * on `stream` other than pg_lauum waits for this work before it starts, so the caller needs no extra synchronisation. */
 int pg_alpha_nlml_async(pg_handle h, int dtype, int n_real, int n, const void* L, long ldl, const void* Minv, long ldm, const void* y,
@@ -176,9 +179,9 @@ int pg_sqdist_argmin(pg_handle h, int dtype, const void* X, long ldx, int n, con
 /* zero the strictly upper triangle (export of krnchd with torch.cholesky's layout) */
 int pg_tril(pg_handle h, int dtype, int n, void* A, long lda, void* stream);
 
-/* pg_potrf overlaps its panel chain (auxiliary high-priority stream inside the handle) with the trailing update
- * on the caller's stream; all work is joined back onto the caller's stream before pg_potrf returns.  on = 0 keeps
- * everything on the caller's stream (default 1). */
+/* pg_potrf overlaps its panel chain (the handle's panel and rows streams) with the trailing update (the handle's CU-masked
+ * update stream); all work is joined back onto the caller's stream before pg_potrf returns.  on = 0 keeps everything on the
+ * caller's stream (default 1); the two schedules agree to rounding. */
 int pg_set_lookahead(pg_handle h, int on);
 
 /* width of pg_potrf's outer column panel: 0 (default) = chosen from n (512 / 1024 / 2048 columns), otherwise a
@@ -188,6 +191,13 @@ int pg_set_outer_panel(pg_handle h, int columns);
 /* GEMM-core profiling for bench.py's roofline leg: events around every MFMA GEMM launch */
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
+
+/* The flag-coupled chain (csrc/chainstep.hip) needs kernels of two of the handle's streams to run at the same time.  pg_create
+ * probes that once (2 ms at most) and switches the chain off for the handle where kernels run one at a time -- a counter-collecting
+ * profiler (rocprofv3 --pmc), serialising debug settings -- so that the factorisation falls back to its classic chain instead of
+ * reporting info = -1.  pg_set_coupled_chain overrides (on = 1 has no effect without a rows stream); pg_coupled_chain reads it. */
+int pg_set_coupled_chain(pg_handle h, int on);
+int pg_coupled_chain(pg_handle h);
 
 /* how many outer panels of the handle's LAST pg_potrf / pg_potrf_trtri ran on the flag-coupled chain (0: classic chain only;
  * the coupled chain needs the look-ahead schedule and a caller stream that is a real non-blocking stream) -- tests / diagnostics */

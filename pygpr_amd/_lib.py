@@ -66,6 +66,8 @@ _SIGS = {
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
     "pg_last_coupled_panels": (_i, [_vp]),
+    "pg_set_coupled_chain": (_i, [_vp, _i]),
+    "pg_coupled_chain": (_i, [_vp]),
     "pg_leaf_raw": (_i, [_vp, _i, _vp, _l, _vp, _l, _vp, _i, _vp]),
     "pg_gemm_raw": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _l, _vp, _l, _d, _vp, _l, _i, _i, _i, _vp]),
 }

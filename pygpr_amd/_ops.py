@@ -268,6 +268,12 @@ class HipOps:
     def set_outer_panel(self, columns):
         _lib.check(self.lib.pg_set_outer_panel(self.h, int(columns)), "pg_set_outer_panel")
 
+    def set_coupled_chain(self, on):
+        _lib.check(self.lib.pg_set_coupled_chain(self.h, int(on)), "pg_set_coupled_chain")
+
+    def coupled_chain(self):
+        return int(self.lib.pg_coupled_chain(self.h))
+
     def last_coupled_panels(self):
         return int(self.lib.pg_last_coupled_panels(self.h))
 

@@ -103,6 +103,41 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     return rc;
 }
 
+// Do kernels of the panel stream and the rows stream run at the same time here?  The coupled chain needs that: its leaf is
+// resident while the rows kernel that publishes its tile is still queued on the other stream.  A counter-collecting profiler
+// (rocprofv3 --pmc) or a serialising debug setting runs one kernel at a time; the chain's bounded waits would then expire and the
+// factorisation report info = -1.  Probe once per handle: a waiter on the panel stream, enqueued FIRST, then the setter on the rows
+// stream.  Concurrent queues: the waiter sees the flag within microseconds.  One kernel at a time: it gives up after ~2 ms.
+__global__ void pg_probe_wait_kernel(int* flag, int* seen) {
+    int ok = 0;
+    for (int it = 0; it < 4096 && !ok; ++it) {
+        ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __hip_atomic_store(seen, ok ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void pg_probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+static int probe_concurrent_queues(pg_ctx* c) {
+    int* words = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&words), 64, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    words[0] = 0;
+    words[1] = 0;
+    int* dwords = nullptr;
+    int ok = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dwords), words, 0) == hipSuccess) {
+        hipLaunchKernelGGL(pg_probe_wait_kernel, dim3(1), dim3(1), 0, c->aux, dwords, dwords + 1);
+        hipLaunchKernelGGL(pg_probe_set_kernel, dim3(1), dim3(1), 0, c->rows, dwords);
+        if (hipStreamSynchronize(c->aux) == hipSuccess && hipStreamSynchronize(c->rows) == hipSuccess) ok = words[1] == 1;
+    }
+    (void)hipGetLastError();
+    (void)hipHostFree(words);
+    return ok;
+}
+
 extern "C" {
 
 int pg_version(void) { return 100; }
@@ -177,6 +212,7 @@ int pg_create(pg_handle* h) {
             (void)hipGetLastError();
         }
     }
+    c->coupled = (c->rows && probe_concurrent_queues(c)) ? 1 : 0;
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
@@ -472,6 +508,12 @@ int pg_profile(pg_handle h, int on) {
     h->prof_on = on;
     return 0;
 }
+int pg_set_coupled_chain(pg_handle h, int on) {
+    NEED(h, "null handle");
+    h->coupled = (on && h->rows) ? 1 : 0;
+    return 0;
+}
+int pg_coupled_chain(pg_handle h) { return h ? h->coupled : -1; }
 int pg_last_coupled_panels(pg_handle h) {
     if (!h) return -1;
     return h->last_coupled;

@@ -25,6 +25,8 @@ struct pg_ctx {
     int npool;
     int lookahead;            // 0 disables the two-stream Cholesky (default 1)
     int nbo;                  // outer panel of the Cholesky; 0 = chosen from n (pg_set_outer_panel / PG_NBO)
+    int coupled;              // the flag-coupled chain may be used (pg_set_coupled_chain; cleared by pg_create when kernels of the
+                              // panel and rows streams do not run concurrently here, e.g. under a counter-collecting profiler)
     int last_coupled;         // panels the last factorisation ran on the flag-coupled chain (chainstep.hip); tests / diagnostics
     int panel_mode;           // how the rows below an outer panel ride its 128-column steps (linalg.hip, PG_PANEL_MODE)
     int side_pending;         // side-stream work (pg_alpha_nlml_async) that the next reader of its outputs must wait for: ev[5]

@@ -494,16 +494,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // that configuration keeps the classic chain.
     static const int sync_env = getenv("PG_SYNC_ROWS") ? atoi(getenv("PG_SYNC_ROWS")) : -1;
     const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && ctx->bg && n > 8192) ? 0 : 8192);
-    // The rows stream is the handle's own (capi.hip).  Without one (PG_ROWS_STREAM=0) the caller's stream serves, if it is a
-    // real non-blocking stream: work on the null stream would wait for the CU-masked update stream, which can only be created
-    // blocking.
-    hipStream_t rows_stream = ctx->rows;
-    if (!rows_stream && st != nullptr && st != hipStreamLegacy && st != hipStreamPerThread) {
-        unsigned int fl = 0;
-        if (hipStreamGetFlags(st, &fl) == hipSuccess && (fl & hipStreamNonBlocking)) rows_stream = st;
-        else (void)hipGetLastError();
-    }
-    const bool want_cp = ctx->lookahead && !ctx->prof_on && rows_stream && sync_rows > 0 && ctx->panel_mode == 0;
+    hipStream_t rows_stream = ctx->rows;      // the handle's own (capi.hip)
+    const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
     static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 512;
     for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, cs_panel) : NBO) pb.push_back(c);

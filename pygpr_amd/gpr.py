@@ -25,6 +25,14 @@ _CHUNK = 8192  # test points per device batch
 
 
 def _lin_alg_error(info: int, note: str = ""):
+    if int(info) < 0:
+        # not a property of the matrix: a bounded wait inside the factorisation's flag-coupled chain expired, i.e. kernels of the
+        # library's streams did not run concurrently (pg_create probes for that; include/pygpr_hip.h: pg_set_coupled_chain)
+        err = RuntimeError("pygpr_amd: the factorisation's coupled chain timed out (info = %d): kernels of different streams do "
+                           "not run concurrently in this environment; call pygpr_amd._ops.get_ops().set_coupled_chain(0) or "
+                           "set PG_SYNC_ROWS=0%s" % (int(info), note))
+        err.pg_info = int(info)
+        return err
     err = torch.linalg.LinAlgError(
         "cholesky: The factorization could not be completed because the input is not positive-definite "
         "(the leading minor of order %d is not positive-definite)%s." % (info, note))

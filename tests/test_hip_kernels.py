@@ -729,3 +729,22 @@ def test_coupled_chain_from_a_side_stream_caller(ops):
         lower = torch.tril(ad).cpu().numpy()          # on the side stream, behind the factorisation
     assert int(info.item()) == 0 and coupled == 6
     np.testing.assert_allclose(lower, np.linalg.cholesky(a), atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_coupled_chain_switch_and_probe(ops):
+    """pg_create's probe found concurrent queues on a plain run (the chain is on); switching it off gives the classic chain
+    and the same factor to rounding."""
+    assert ops.coupled_chain() == 1
+    n = 3072
+    a = spd(n, np.random.default_rng(17))
+    outs = []
+    try:
+        for on in (1, 0):
+            ops.set_coupled_chain(on)
+            ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
+            assert info == 0 and (coupled == 6 if on else coupled == 0)
+            outs.append(np.tril(host(ad)))
+    finally:
+        ops.set_coupled_chain(1)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-13)

@@ -15,4 +15,4 @@ hp = np.concatenate([[1.0], np.ones(d), [0.1]])
 for i in range(2):
     l, g = mle.loss_and_grad(hp * (1 + 1e-3 * i))
 torch.cuda.synchronize()
-print("loss", float(l))
+print("loss", float(l), "coupled chain enabled:", pg._ops.get_ops().coupled_chain(), "panels coupled in the last call:", pg._ops.get_ops().last_coupled_panels())
