@@ -143,6 +143,12 @@ int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* h
 int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* Ks, long ldks, const void* Minv,
                       long ldm, const void* alpha, void* mean, void* var, double kss, void* work, void* stream);
 
+/* The same from the cross-covariance stored test-point-major, Kt[m_pad x n_pad] = k(Xp, X) (build it with pg_kernel_build(Xp, X)):
+ * the variance product then reads both operands K-contiguously (the faster NT form of the GEMM core) and the mean is a row-wise
+ * mat-vec.  Same results to rounding; work: (n_pad/64) * m_pad elements. */
+int pg_predict_mean_q_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Kt, long ldkt, const void* Minv,
+                         long ldm, const void* alpha, void* mean, void* var, double kss, void* work, void* stream);
+
 /* Dense product V = Minv Ks written out (needed for the full predictive covariance, gpr.py:108-120),
  * and C = C - V^T V on m_pad x m_pad (lower_only != 0: tiles on/below the diagonal only). */
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks,

@@ -52,6 +52,7 @@ _SIGS = {
     "pg_nlml_grad_worksize": (_l, [_i, _i]),
     "pg_nlml_grad": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
     "pg_predict_mean_q": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _d, _vp, _vp]),
+    "pg_predict_mean_q_kt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _d, _vp, _vp]),
     "pg_trmm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
     "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),

@@ -198,6 +198,15 @@ class HipOps:
                                               _p(mean), _p(q), float(kss), _p(work), self._st()),
                    "pg_predict_mean_q")
 
+    def predict_mean_q_kt(self, kt, minv, alpha, mean, var, kss, work):
+        """The same from kt [m_pad, n_pad] = k(xp, x) (test-point-major): mean = Kt alpha; var = kss - colsum((Minv Kt^T)^2)."""
+        q = var
+        self._chk(kt, minv, alpha, mean, q, work)
+        _lib.check(self.lib.pg_predict_mean_q_kt(self.h, _code(kt.dtype), kt.shape[1], kt.shape[0], _p(kt), kt.stride(0),
+                                                 _p(minv), minv.stride(0) if minv is not None else 0, _p(alpha),
+                                                 _p(mean), _p(q), float(kss), _p(work), self._st()),
+                   "pg_predict_mean_q_kt")
+
     def trmm_lower(self, minv, ks, v):
         self._chk(minv, ks, v)
         _lib.check(self.lib.pg_trmm_lower(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(minv), minv.stride(0),

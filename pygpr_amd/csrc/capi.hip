@@ -405,6 +405,18 @@ int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* 
                                         (const float*)alpha, (float*)mean, (float*)q, kss, (float*)work));
 }
 
+int pg_predict_mean_q_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Kt, long ldkt, const void* Minv, long ldm,
+                         const void* alpha, void* mean, void* q, double kss, void* work, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Kt && alpha && mean && work, "null pointer");
+    NEED(!q || Minv, "variance needs Minv");
+    DISPATCH(dtype,
+             pg_predict_mean_q_kt_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Kt, ldkt, (const double*)Minv, ldm,
+                                            (const double*)alpha, (double*)mean, (double*)q, kss, (double*)work),
+             pg_predict_mean_q_kt_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Kt, ldkt, (const float*)Minv, ldm,
+                                           (const float*)alpha, (float*)mean, (float*)q, kss, (float*)work));
+}
+
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks, long ldks,
                   void* V, long ldv, void* stream) {
     JOIN(h, stream);

@@ -15,9 +15,11 @@
 //                                    the NCRIT workgroups owning tile (k+1, k+1) publish it (diag[k+1] += 1)
 //
 // so between two leaves lie one K = 128 solve, one K = 128 product and three flag hops instead of two full launches, and the
-// long part of the update runs while the leaf does.  Host enqueue order is leaf(k), rows(k), leaf(k+1), ...: a topological order,
-// so the pair makes progress even if the two streams were served by one hardware queue.  Every spin is bounded: on expiry a
-// sticky timeout word ends all later spins at once and *info is set to -1 (the caller sees a failed factorisation, not a hang).
+// long part of the update runs while the leaf does.  The scheme NEEDS the two queues to run concurrently: where kernels are
+// executed one at a time in an order of the tool's choosing (a counter-collecting profiler), leaf(k+1) can be started before the
+// rows(k) it waits for.  pg_create probes for that once and keeps the classic chain there (capi.hip); beyond that every spin is
+// bounded: on expiry a sticky timeout word ends all later spins at once and *info is set to -1 (the caller sees a failed
+// factorisation, not a hang -- seen exactly once, under rocprofv3 --pmc before the probe existed).
 // Every kernel performs all of its signals whatever it saw (bad pivot, timeout), so nothing downstream waits for ever.
 #include "chainstep.h"
 

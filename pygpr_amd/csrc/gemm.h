@@ -36,6 +36,7 @@ enum GemmVariant {
     GEMM_NT_32x64 = 8,  // the two skinny products of the Cholesky chain when they have fewer than two 64-row workgroups per
     GEMM_NT_32x128 = 9, // CU: half the row tile (and a 32-deep K tile) puts two waves on every SIMD (45 % -> MFMA use)
     GEMM_TT_64 = 10,    // TT with 64 x 64 tiles: the small levels of the triangular inverse (few, long 128 x 128 tiles otherwise)
+    GEMM_NT_128_SS = 12, // the same epilogue on C = A B^T: the cross-covariance stored test-point-major (K-contiguous B operand)
     GEMM_NT_32x32 = 11  // NT with 32 x 32 tiles and a 64-deep K tile: the chain's U product in the chain-bound tail of the Cholesky
                         // (latency per launch, not throughput, is what counts there: 4x the workgroups, half the K iterations)
 };

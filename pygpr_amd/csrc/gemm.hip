@@ -295,7 +295,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     // fp32 keeps four waves (its 64 x 64 wave tile needs half the registers: already four waves per SIMD; eight were 3 % slower).
     static const int w4env = getenv("PG_GEMM_W4") ? atoi(getenv("PG_GEMM_W4")) : 0;
     static const int ss4 = getenv("PG_SS_W4") ? atoi(getenv("PG_SS_W4")) : 1;   // the column-sum epilogue: four waves (8.63 vs 8.85 ms, config-2 predict)
-    const bool w4 = w4env || sizeof(T) == 4 || (variant == GEMM_NN_128_SS && ss4);
+    const bool w4 = w4env || sizeof(T) == 4 || ((variant == GEMM_NN_128_SS || variant == GEMM_NT_128_SS) && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
     const bool prof = ctx && ctx->prof_on;
@@ -306,6 +306,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         case GEMM_NT_RP: rc = launch<T, false, true, 64, 256, 0>(st, p); break;
         case GEMM_NN_128: rc = w4 ? launch<T, false, false, 128, 128, 0>(st, p) : launch<T, false, false, 128, 128, 0, BK, 8>(st, p); break;
         case GEMM_TN_128: rc = w4 ? launch<T, true, false, 128, 128, 0>(st, p) : launch<T, true, false, 128, 128, 0, BK, 8>(st, p); break;
+        case GEMM_NT_128_SS: rc = w4 ? launch<T, false, true, 128, 128, 1>(st, p) : launch<T, false, true, 128, 128, 1, BK, 8>(st, p); break;
         case GEMM_NN_128_SS: rc = w4 ? launch<T, false, false, 128, 128, 1>(st, p) : launch<T, false, false, 128, 128, 1, BK, 8>(st, p); break;
         case GEMM_TT_128: rc = w4 ? launch<T, true, true, 128, 128, 0>(st, p) : launch<T, true, true, 128, 128, 0, BK, 8>(st, p); break;
         case GEMM_NT_64: rc = launch<T, false, true, 64, 64, 0>(st, p); break;

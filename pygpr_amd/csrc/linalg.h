@@ -15,6 +15,9 @@ template <typename T> int pg_nlml_value_t(hipStream_t, int n, const T* L, long l
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx*, hipStream_t, int n, int m, const T* Ks, long ldks, const T* M, long ldm, const T* alpha,
                         T* mean, T* q, double kss, T* work);
+template <typename T>
+int pg_predict_mean_q_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* Kt, long ldkt, const T* M, long ldm, const T* alpha,
+                        T* mean, T* q, double kss, T* work);
 template <typename T> int pg_trmm_lower_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, const T* Ks, long ldks, T* V, long ldv);
 template <typename T> int pg_syrk_tn_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only);
 template <typename T>

@@ -487,7 +487,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // Its rows kernels update a block column by the previous panel too (the window of the left-looking product starts there), so
     // the per-panel update Sa disappears from the critical path; panels are at most 512 wide there to keep that product
     // shorter than a leaf.
-    // Measured (MI355X, fp64, build + factor): n = 4096 2.28 -> 1.77 ms, 8192 6.30 -> 5.37, 16384 30.75 -> 29.42 with the last 8192
+    // Measured (MI355X, fp64, build + factor): n = 4096 2.28 -> 1.68 ms, 8192 6.30 -> 5.19, 16384 30.75 -> 29.13 with the last 8192
     // rows coupled (2048: 30.41, 4096: 30.03, 6144: 29.62, 12288: 30.14, all: 31.48 -- while the trailing update still fills the
     // chip the resident rows workgroups hold the slots it needs).  With the experimental background inverse of the fused call
     // running (PG_BG_STREAM=1), the rows workgroups starve beside its long tiles: n = 16384 fused 51.5 -> 52.5 ms, so above 8192
@@ -790,6 +790,46 @@ int pg_alpha_nlml_async_t(pg_ctx* ctx, hipStream_t st, int n_real, int n, const 
     return 0;
 }
 
+// y[j] = sum_i A[j][i] x[i] for a row-major A [m x n]: one wave per row, 16-byte loads (n a multiple of 256)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ A, long lda, int n, const T* __restrict__ x,
+                                                        T* __restrict__ y) {
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const T* a = A + (long)row * lda;
+    T s = (T)0;
+    for (int k = lane * VE; k < n; k += 64 * VE) {
+        const vec_t av = *reinterpret_cast<const vec_t*>(a + k);
+        const vec_t xv = *reinterpret_cast<const vec_t*>(x + k);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s += av[e] * xv[e];
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s;
+}
+
+// The same with the cross-covariance stored test-point-major: Kt[m_pad x n_pad] = k(Xp, X).  The variance product then has a
+// K-contiguous B operand (C = Minv Kt^T, the NT form: 71 vs 66 TFLOP/s for NN on uniform products) and the mean is a row-wise
+// mat-vec.
+template <typename T>
+int pg_predict_mean_q_kt_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Kt, long ldkt, const T* M, long ldm,
+                           const T* alpha, T* mean, T* q, double kss, T* work) {
+    if (n % PG_PAD || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q_kt: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
+    hipLaunchKernelGGL(gemv_rows_kernel<T>, dim3(m / 4), dim3(256), 0, st, Kt, ldkt, n, alpha, mean);
+    LAUNCH_CHECK();
+    if (q) {
+        GemmP<T> p = gp0<T>();
+        p.M = n; p.N = m; p.K = n; p.A = M; p.lda = ldm; p.B = Kt; p.ldb = ldkt; p.khi = 1;
+        p.part = work; p.ldp = m;
+        int rc = pg_gemm<T>(ctx, st, GEMM_NT_128_SS, p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0, kss, -1.0, 0);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 template <typename T>
 int pg_predict_mean_q_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Ks, long ldks, const T* M, long ldm,
                         const T* alpha, T* mean, T* q, double kss, T* work) {
@@ -880,6 +920,8 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \
                                         T*, double, T*);                                                               \
+    template int pg_predict_mean_q_kt_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \
+                                           T*, double, T*);                                                            \
     template int pg_trmm_lower_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, T*, long);         \
     template int pg_syrk_tn_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, T*, long, int);                     \
     template int pg_grbcm_terms_t<T>(hipStream_t, int, const T*, const T*, const T*, int, int, double*, long, double*, \

@@ -245,13 +245,13 @@ class Exact_GP(GPR):
             xq = xpd[s: s + _CHUNK]
             mc = xq.shape[0]
             m_pad = pad_to(mc)
-            ks = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
-            ops.kernel_build(spec, e.hp, e.x, xq, ks)
+            kt = ops.empty(m_pad, e.n_pad, dtype=self.dtype)   # K* test-point-major: k(xp, x) (the kernels are symmetric)
+            ops.kernel_build(spec, e.hp, xq, e.x, kt)
             mu = ops.empty(m_pad, dtype=self.dtype)
             vq = ops.empty(m_pad, dtype=self.dtype) if want == "diag" else None
             work = ops.empty((e.n_pad // 64) * m_pad, dtype=self.dtype)
-            ops.predict_mean_q(ks, self._minv(e) if want == "diag" else None, e.alpha, mu, vq,
-                               self._kss_diag(b), work)
+            ops.predict_mean_q_kt(kt, self._minv(e) if want == "diag" else None, e.alpha, mu, vq,
+                                  self._kss_diag(b), work)
             mean[s: s + mc] = mu[:mc]
             if want == "diag":
                 var[s: s + mc] = vq[:mc]

@@ -169,6 +169,9 @@ class OracleOps:
             v = np.tril(_np(minv).astype(np.float64)) @ k
             var.copy_(torch.from_numpy(kss - (v * v).sum(0)))
 
+    def predict_mean_q_kt(self, kt, minv, alpha, mean, var, kss, work):
+        self.predict_mean_q(torch.from_numpy(np.ascontiguousarray(_np(kt).T)), minv, alpha, mean, var, kss, work)
+
     def trmm_lower(self, minv, ks, v):
         v.copy_(torch.from_numpy(np.tril(_np(minv).astype(np.float64)) @ _np(ks).astype(np.float64)))
 

@@ -592,6 +592,14 @@ def test_predict_mean_q(ops):
     mu_ref, var_ref = orc.gp_predict(covs, hp, x, y, xp, "diag", form="direct")
     np.testing.assert_allclose(host(mean)[:m], mu_ref, atol=1e-10)
     np.testing.assert_allclose(host(q)[:m], var_ref, atol=1e-11)
+    # the same from the cross-covariance stored test-point-major (the form the class surface uses)
+    kt = ops.empty(mpad, npad)
+    ops.kernel_build(spec, hpd, xpd, xd, kt)
+    np.testing.assert_array_equal(host(kt)[:m, :n], host(ks)[:n, :m].T)
+    mean2, q2 = ops.empty(mpad), ops.empty(mpad)
+    ops.predict_mean_q_kt(kt, minv, alpha, mean2, q2, kss, work)
+    np.testing.assert_allclose(host(mean2)[:m], mu_ref, atol=1e-10)
+    np.testing.assert_allclose(host(q2)[:m], var_ref, atol=1e-11)
     # full covariance pieces: V = Minv Ks, C = Kss - V^T V
     v = ops.empty(npad, mpad)
     ops.trmm_lower(minv, ks, v)
