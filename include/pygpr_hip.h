@@ -51,10 +51,9 @@ typedef struct pg_covspec {
 
 int pg_version(void);
 const char* pg_last_error(void);
-/* A handle owns three HIP streams (panel / rows / update) and a pool of events.  Streams are a budget on MI355X / ROCm 7.2: with
- * a fifth hardware queue alive in the process (the caller's counts) the factorisation's look-ahead loses 20-60 %, so keep your own
- * GPU work on ONE stream -- any stream, the legacy default one included ("the stream budget").  Release the handle with
- * pg_destroy when done; handles still alive at process exit are destroyed by the library itself (a C atexit handler registered by the
+/* A handle owns three HIP streams (panel / rows / update; the update stream is CU-masked) and a pool of events, and works from any
+ * caller stream, the legacy default one included.  Release the handle with pg_destroy when
+ * done; handles still alive at process exit are destroyed by the library itself (a C atexit handler registered by the
  * first pg_create, so it runs before the HIP runtime's own teardown).  pg_destroy on an already released handle is a no-op. */
 int pg_create(pg_handle* h);
 int pg_destroy(pg_handle h);
@@ -201,7 +200,9 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
 /* The flag-coupled chain (csrc/chainstep.hip) needs kernels of two of the handle's streams to run at the same time.  pg_create
  * probes that once (2 ms at most) and switches the chain off for the handle where kernels run one at a time -- a counter-collecting
  * profiler (rocprofv3 --pmc), serialising debug settings -- so that the factorisation falls back to its classic chain instead of
- * reporting info = -1.  pg_set_coupled_chain overrides (on = 1 has no effect without a rows stream); pg_coupled_chain reads it. */
+ * reporting info = -1.  pg_set_coupled_chain(h, 0) switches the chain off AND destroys the rows stream (the handle then owns two
+ * streams);
+ * pg_set_coupled_chain(h, 1) re-creates the stream and probes again; pg_coupled_chain reads the state. */
 int pg_set_coupled_chain(pg_handle h, int on);
 int pg_coupled_chain(pg_handle h);
 

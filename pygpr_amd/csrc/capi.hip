@@ -184,11 +184,10 @@ int pg_create(pg_handle* h) {
             c->lookahead = 0;
             (void)hipGetLastError();
         }
-        // Streams are a budget: with a FIFTH hardware queue alive in the process (the caller's stream counts) the look-ahead loses
-        // its effect -- the chain's kernels then wait behind the update's tiles: 6.4 -> 10.4 ms at n = 8192 whichever stream is
-        // the extra one and whether or not it ever runs anything (stream count).  The handle therefore owns three: panel,
-        // rows, update.  The background stream of the fused factor-and-invert call (PG_BG_STREAM=1) is an experiment that needs the
-        // rows stream switched off (PG_ROWS_STREAM=0): its overlap returned 0.5 ms of 8.7 at n = 8192 and nothing at 16384.
+        // The background stream of the fused factor-and-invert call (PG_BG_STREAM=1, replaces the rows stream) is an experiment:
+        // its overlap returned 0.5 ms of 8.7 at n = 8192 and nothing at 16384, and a handle with TWO CU-masked streams is
+        // fragile -- any fifth hardware queue in the process (a second stream of the caller's is enough) then costs the
+        // look-ahead 20-60 %, which the current panel / rows / update set does not show with up to seven queues.
         c->bg = nullptr;
         const char* envbg = getenv("PG_BG_STREAM");
         if (envbg && atoi(envbg)) {
@@ -522,7 +521,25 @@ int pg_profile(pg_handle h, int on) {
 }
 int pg_set_coupled_chain(pg_handle h, int on) {
     NEED(h, "null handle");
-    h->coupled = (on && h->rows) ? 1 : 0;
+    if (!on) {
+        // off also RELEASES the rows stream (the handle then owns two streams)
+        if (h->rows) {
+            PG_CHECK(hipStreamSynchronize(h->rows));
+            PG_CHECK(hipStreamDestroy(h->rows));
+            h->rows = nullptr;
+        }
+        h->coupled = 0;
+        return 0;
+    }
+    if (!h->rows && h->upd && !h->bg) {
+        int prio_lo = 0, prio_hi = 0;
+        PG_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        if (hipStreamCreateWithPriority(&h->rows, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+            h->rows = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    h->coupled = (h->rows && probe_concurrent_queues(h)) ? 1 : 0;
     return 0;
 }
 int pg_coupled_chain(pg_handle h) { return h ? h->coupled : -1; }
