@@ -88,6 +88,14 @@ int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, i
 int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
                    void* stream);
 
+/* pg_kernel_build(lower_only = 1, symmetric, one pg_covspec) folded into pg_potrf (Minv == NULL) / pg_potrf_trtri: K + jitter I
+ * -> A, then its factor in place (covar.py:50-62 + gpr.py:67-69 / loss.py:38-39,63-64,96-97 in one call).  The first outer panel's
+ * columns are built before the factorisation's look-ahead starts, the rest on the update stream while the first panel's chain
+ * runs (that chain has the chip to itself otherwise).  Same A and factor as the two separate calls. */
+int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
+                         double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
+                         void* stream);
+
 /* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
  * work: pg_potrs_vec_worksize(dtype, n) elements (2 n below n = 2048; above, also the 1024-wide diagonal block
  * inverses the blocked sweeps multiply with). */

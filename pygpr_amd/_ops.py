@@ -119,6 +119,22 @@ class HipOps:
         _lib.check(self.lib.pg_potrf(self.h, _code(a.dtype), a.shape[0], _p(a), a.stride(0), _p(invd), _p(info),
                                      self._st()), "pg_potrf")
 
+    def build_factor(self, spec, hp, x, a, invd, info, minv=None, jitter=JITTER):
+        """a <- k(x, x) + jitter I (lower tiles), then its Cholesky factor in place (and minv <- L^-1 if given): kernel_build
+        folded into potrf / potrf_trtri -- the build of everything right of the first panel overlaps that panel's chain.  A
+        Compose longer than one pg_covspec falls back to the separate calls."""
+        passes = _passes(spec)
+        if len(passes) != 1 or os.environ.get("PG_NO_FOLD"):
+            self.kernel_build(spec, hp, x, None, a, lower_only=True, jitter=jitter)
+            return self.potrf_trtri(a, invd, info, minv) if minv is not None else self.potrf(a, invd, info)
+        self._chk(hp, x, a, invd, info, minv)
+        assert hp.dtype == torch.float64
+        n, d = x.shape
+        _lib.check(self.lib.pg_build_potrf_trtri(
+            self.h, _code(a.dtype), C.byref(passes[0]), _p(hp), _p(x), x.stride(0), n, d, float(jitter), _p(a), a.stride(0),
+            a.shape[0], _p(invd), _p(info), _p(minv), minv.stride(0) if minv is not None else 0, self._st()),
+            "pg_build_potrf_trtri")
+
     def potrf_trtri(self, a, invd, info, minv):
         """Cholesky in place + minv = L^-1, fused so that part of the inverse overlaps the factorisation's tail."""
         self._chk(a, invd, info, minv)

@@ -138,6 +138,14 @@ static int probe_concurrent_queues(pg_ctx* c) {
     return ok;
 }
 
+template <typename T>
+static int build_potrf_t(pg_handle h, hipStream_t st, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
+                         double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm) {
+    BuildReq<T> br;
+    br.spec = spec; br.hp = hp; br.X = (const T*)X; br.ldx = ldx; br.n_real = n; br.d = d; br.jitter = jitter;
+    return pg_potrf_t<T>(h, st, n_pad, (T*)A, lda, (T*)inv_diag, info, (T*)Minv, ldm, &br);
+}
+
 extern "C" {
 
 int pg_version(void) { return 100; }
@@ -275,6 +283,18 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
     if (check_spec(spec, __func__)) return -1;
     DISPATCH(dtype, pg_kgrad<double>(ST(stream), *spec, hp, (const double*)X, ldx, n, d, (double*)dK),
              pg_kgrad<float>(ST(stream), *spec, hp, (const float*)X, ldx, n, d, (float*)dK));
+}
+
+int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
+                         double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
+                         void* stream) {
+    JOIN(h, stream);
+    NEED(h && hp && X && A && inv_diag && info, "null pointer");
+    if (check_spec(spec, __func__, true)) return -1;
+    NEED(n >= 0 && n_pad >= n && lda >= n_pad, "inconsistent sizes");
+    NEED(lda % (dtype == PG_F64 ? 2 : 4) == 0, "lda must keep rows 16-byte aligned");
+    DISPATCH(dtype, build_potrf_t<double>(h, ST(stream), spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm),
+             build_potrf_t<float>(h, ST(stream), spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm));
 }
 
 long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize_impl(n); }

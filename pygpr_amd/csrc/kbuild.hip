@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                                                         const T* __restrict__ Xr, long ldr, int nr,
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
                                                         int symmetric, int lower_only, int accumulate, double jitter,
-                                                        T* __restrict__ K, long ldk) {
-    const int tc = blockIdx.x, tr = blockIdx.y;
+                                                        T* __restrict__ K, long ldk, int ctile0) {
+    const int tc = blockIdx.x + ctile0, tr = blockIdx.y;   // ctile0: first column tile of the window this launch builds
     // symmetric builds evaluate only tiles on/below the diagonal; lower_only == 0 also writes the mirror image
     if (symmetric && tc > tr) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
               const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,
-              long ldk, int rows_pad, int cols_pad) {
+              long ldk, int rows_pad, int cols_pad, int col0, int col1) {
     if (rows_pad % KT || cols_pad % KT || d < 1 || d > PG_MAX_DIM) {
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
@@ -188,16 +188,27 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
-    dim3 grid(cols_pad / KT, rows_pad / KT);
+    // columns [col0, col1) only (col1 <= 0: all): a lower-only symmetric build in two column windows lets the factorisation
+    // start on the first panel while the rest is still being written (pg_potrf_t, BuildReq)
+    if (col1 <= 0) { col0 = 0; col1 = cols_pad; }
+    if (col0 % KT || col1 % KT || col0 < 0 || col1 > cols_pad || col0 >= col1) {
+        pg_set_error("pg_kbuild: bad column window [%d, %d)", col0, col1);
+        return -2;
+    }
+    if (symmetric && !lower_only && (col0 != 0 || col1 != cols_pad)) {
+        pg_set_error("pg_kbuild: a mirrored build cannot be windowed");
+        return -2;
+    }
+    dim3 grid((col1 - col0) / KT, rows_pad / KT);
     hipLaunchKernelGGL(pg_kbuild_kernel<T>, grid, dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                       symmetric, lower_only, accumulate, jitter, K, ldk);
+                       symmetric, lower_only, accumulate, jitter, K, ldk, col0 / KT);
     PG_CHECK(hipGetLastError());
     return 0;
 }
 template int pg_kbuild<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int,
-                               const double*, long, int, int, int, int, int, double, double*, long, int, int);
+                               const double*, long, int, int, int, int, int, double, double*, long, int, int, int, int);
 template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int,
-                              const float*, long, int, int, int, int, int, double, float*, long, int, int);
+                              const float*, long, int, int, int, int, int, double, float*, long, int, int, int, int);
 
 // ------------------------------------------------------------------------------------------------
 // dK stack of the public Covar.kernel_and_grad (covar.py:64-81,169-206,247-269): dK[p][i][j] for

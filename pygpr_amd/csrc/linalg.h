@@ -1,7 +1,19 @@
 #pragma once
 #include "common.h"
+#include "pygpr_hip.h"
 long pg_potrf_worksize_impl(int n);
-template <typename T> int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm);
+// A covariance build folded into the factorisation (pg_build_potrf_trtri): A is written by pg_potrf_t itself, the first outer
+// panel's columns before the look-ahead starts and the rest on the update stream while the first panel's chain runs.
+template <typename T> struct BuildReq {
+    const pg_covspec* spec;
+    const double* hp;
+    const T* X;
+    long ldx;
+    int n_real, d;
+    double jitter;
+};
+template <typename T>
+int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build = nullptr);
 template <typename T> int pg_potrs_vec_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work);
 template <typename T> int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0);
 long pg_potrs_vec_worksize_impl(int n);

@@ -13,6 +13,7 @@
 #include "gemm.h"
 #include "leaf.h"
 #include "chainstep.h"
+#include "kbuild.h"
 #include "linalg.h"
 #include <cmath>
 #include <cstdlib>
@@ -473,7 +474,7 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
 // whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
 // the caller's stream at the end.
 template <typename T>
-int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm) {
+int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
     const int NBO = pg_nbo(ctx, n);
@@ -506,11 +507,26 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     hipStream_t us = la ? ctx->upd : st;   // update stream
     hipEvent_t ev;
     int rc;
+    // folded covariance build: the first panel's columns now, the rest on the update stream beside the first panel's chain
+    const bool build_split = build && la && npan >= 2;
+    if (build) {
+        const int c1 = build_split ? pb[1] : n;
+        if ((rc = pg_kbuild<T>(st, *build->spec, build->hp, build->X, build->ldx, build->n_real, build->X, build->ldx, build->n_real,
+                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, 0, c1)))
+            return rc;
+    }
     if (la) {
         if ((rc = pool_event(ctx, 0, &ev))) return rc;
         PG_CHECK(hipEventRecord(ev, st));
         PG_CHECK(hipStreamWaitEvent(ps, ev, 0));
         PG_CHECK(hipStreamWaitEvent(us, ev, 0));
+    }
+    if (build_split) {
+        if ((rc = pg_kbuild<T>(us, *build->spec, build->hp, build->X, build->ldx, build->n_real, build->X, build->ldx, build->n_real,
+                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, pb[1], n)))
+            return rc;
+        if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;      // ev_build: every column right of the first panel exists
+        PG_CHECK(hipEventRecord(ev, us));
     }
     // fused L^-1: split the diagonal at `split` columns; the leading part is inverted in the background once its
     // columns are final (after the chain of panel split/NBO - 1), together with the first top-level product
@@ -555,6 +571,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 const int wstart = oc == o_s ? pb[o_s] : pb[oc - 1];   // the classic part applied the panel before the first coupled one
                 if (c == oend && oc >= 2) {                  // first touch of panel oc: Sb(oc - 2) wrote these columns last
                     if ((rc = pool_event(ctx, 2 + 2 * (oc - 2) + 1, &ev))) return rc;
+                    PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+                }
+                if (c == oend && oc == 1 && build_split) {   // first touch of a column the folded build wrote on the update stream
+                    if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
                 if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, f_tmo, info)))
@@ -622,6 +642,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             const long tiles = (long)(p.M / 128) * (p.N / 128);
             if (la && o > 0) {   // these columns were last written by Sb(o-1)
                 if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
+                PG_CHECK(hipStreamWaitEvent(cs, ev, 0));
+            }
+            if (o == 0 && build_split) {   // ... or, for the first panel, by the folded build on the update stream
+                if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
                 PG_CHECK(hipStreamWaitEvent(cs, ev, 0));
             }
             // (64 x 64 below 1024 large tiles; re-swept with the eight-wave 128 x 128 blocks: 256 is 0.4-0.8 ms slower at 16384)
@@ -910,7 +934,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 }
 
 #define INST(T)                                                                                                        \
-    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long);                               \
+    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*);            \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int);                         \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \

@@ -195,19 +195,18 @@ class Exact_GP(GPR):
                     e.invd = ops.potrf_workspace(e.n_pad, self.dtype)
                     e.alpha = ops.empty(e.n_pad, dtype=self.dtype)
                     e.info = torch.zeros(1, dtype=torch.int32, device=ops.device)
-                ops.kernel_build(spec, e.hp, e.x, None, e.chol, lower_only=True, jitter=JITTER)
                 if self.eager_inverse:
                     if e.minv is None:
                         e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
                         e.work = ops.empty((e.n_pad // 256 + 1) * e.n_pad, dtype=self.dtype)
-                    ops.potrf_trtri(e.chol, e.invd, e.info, e.minv)
+                    ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info, e.minv)
                     u = e.work[: e.n_pad]
                     ops.trmv(e.minv, e.y, u, 0)
                     ops.trmv(e.minv, u, e.alpha, 1, e.work[e.n_pad:])
                     e.minv_valid = True
                 else:
                     e.minv_valid = False
-                    ops.potrf(e.chol, e.invd, e.info)
+                    ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info)
                     ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
             for e in experts:   # one sync point after everything is enqueued
                 info = int(e.info.item())

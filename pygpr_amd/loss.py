@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from numpy import ndarray
 
-from ._ops import JITTER, get_ops
+from ._ops import get_ops
 from .covar import layout, spec_of
 from .gpr import GPR, _lin_alg_error
 
@@ -116,16 +116,14 @@ class MLE(Loss):
                 ops.lauum(m, a)
                 ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
             elif want_grad:
-                ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
-                ops.potrf_trtri(a, buf["invd"], buf["info"], m)      # Cholesky + L^-1, overlapped inside the library
+                ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"], m)   # covariance build + Cholesky + L^-1 in one call
                 # alpha = L^-T (L^-1 y) and the NLML value on the library's side stream, beside K^-1 = L^-T L^-1 (lower, over a)
                 ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, buf["val"])
                 ops.lauum(m, a)
                 ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])   # waits for the side stream
                 out[0:1].copy_(buf["val"][0:1])
             else:
-                ops.kernel_build(spec, hp, e.x, None, a, lower_only=True, jitter=JITTER)
-                ops.potrf(a, buf["invd"], buf["info"])
+                ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"])
                 ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
                 ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
             res = out.cpu().numpy()                                   # the one sync + transfer

@@ -112,6 +112,10 @@ class OracleOps:
             idx = np.tril_indices(m.shape[0])
             _np(a)[idx] = low[idx]
 
+    def build_factor(self, spec, hp, x, a, invd, info, minv=None, jitter=1e-7):
+        self.kernel_build(spec, hp, x, None, a, lower_only=True, jitter=jitter)
+        return self.potrf_trtri(a, invd, info, minv) if minv is not None else self.potrf(a, invd, info)
+
     def potrf_trtri(self, a, invd, info, minv):
         self.potrf(a, invd, info)
         if int(info[0]) == 0:

@@ -756,3 +756,38 @@ def test_coupled_chain_switch_and_probe(ops):
     finally:
         ops.set_coupled_chain(1)
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,with_inv", [(1000, False), (3072, True), (10240, False)])
+def test_build_folded_into_the_factorisation(ops, n, with_inv):
+    """pg_build_potrf_trtri == pg_kernel_build(lower_only) + pg_potrf[_trtri]: same matrix, same schedule, the build of the
+    columns right of the first panel merely runs beside that panel's chain -- bit-identical factor (and inverse)."""
+    from pygpr_amd._ops import pad_to
+
+    d = 5
+    covs = [orc.SE, orc.WN]
+    x, _ = orc.synth(n, d, seed=n)
+    hp = np.array([1.0, 0.9, 1.1, 0.8, 1.2, 1.0, 0.1])
+    npad = pad_to(n)
+    spec = _spec(covs, d)
+    hpd, xd = dev(hp), dev(x)
+    outs = []
+    for folded in (False, True):
+        a = ops.empty(npad, npad)
+        a.fill_(float("nan"))
+        invd = ops.potrf_workspace(npad, torch.float64)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        minv = ops.zeros(npad, npad) if with_inv else None
+        if folded:
+            ops.build_factor(spec, hpd, xd, a, invd, info, minv, jitter=1e-7)
+        else:
+            ops.kernel_build(spec, hpd, xd, None, a, lower_only=True, jitter=1e-7)
+            (ops.potrf_trtri(a, invd, info, minv) if with_inv else ops.potrf(a, invd, info))
+        assert int(info.item()) == 0
+        outs.append((np.tril(host(a)), np.tril(host(minv)) if with_inv else None))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    if with_inv:
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    k = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    np.testing.assert_allclose(outs[1][0][:n, :n], np.linalg.cholesky(k), atol=1e-10)
