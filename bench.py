@@ -400,6 +400,20 @@ def main():
                                      "frac_of_fp64_matrix_peak": 8192 ** 3 / 3.0 / t2 / 1e9 / FP64_MATRIX_PEAK_TFLOPS,
                                      "coupled_panels": ops.last_coupled_panels()}
             del a, invd, x2d
+            # a grBCM-expert-sized factorisation: all of it is the latency-bound chain (32 steps of 128 columns)
+            x4d = torch.from_numpy(x2[:4096]).cuda()
+            a = ops.empty(4096, 4096)
+            invd = ops.potrf_workspace(4096, torch.float64)
+
+            def fac4():
+                ops.kernel_build(spec, hpd, x4d, None, a, lower_only=True, jitter=1e-7)
+                ops.potrf(a, invd, info)
+
+            t4l = timed(lambda: ops.kernel_build(spec, hpd, x4d, None, a, lower_only=True, jitter=1e-7), 3)
+            t4 = timed(fac4, 5) - t4l
+            out["cholesky_n4096"] = {"n": 4096, "ms": t4, "us_per_128_column_step": 1e3 * t4 / 32, "tflops": 4096 ** 3 / 3.0 / t4 / 1e9,
+                                     "coupled_panels": ops.last_coupled_panels()}
+            del a, invd, x4d
         gp2 = pg.Exact_GP(torch.from_numpy(x2), torch.from_numpy(y2), cov, eager_inverse=True)   # variances follow
         gp2.set_params(torch.from_numpy(hp))
         xs2 = torch.from_numpy(np.random.default_rng(4321).random((8192, d))).cuda()
