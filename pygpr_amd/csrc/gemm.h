@@ -22,6 +22,7 @@ template <typename T> struct GemmP {
     long ldp;
     const int* info;  // device flag: kernels exit at once when *info != 0 (failed factorisation)
     int noxcd;        // 1: keep launch order instead of the XCD-chunked tile order (experiments)
+    int atomic_c;     // set by pg_gemm (fp64, beta == 1): the epilogue adds into C with no-return atomics instead of load + store
 };
 
 enum GemmVariant {

@@ -219,6 +219,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
                     const int col = n0 + wn * WTN + j * 16 + fr;
                     T* c = C + (long)row * p.ldc + col;
                     T v = alpha * acc[i][j][r];
+                    if (p.atomic_c) {
+                        // beta == 1 (every update of the factorisation): C += alpha A B^T as a no-return fp64 add performed in
+                        // L2.  One add per element, so the same result bit for bit -- but the tile is not read into the CU first:
+                        // the epilogue's serial load -> add -> store chain (64 elements per lane, no registers left to batch the
+                        // loads) was 10 % of a K = 1024 tile.  K = 1024 SYRK 63.8 -> 65.9 TFLOP/s, K = 512 53.5 -> 56.5,
+                        // factorisation at n = 16384 29.2 -> 28.3 ms.
+                        unsafeAtomicAdd(c, v);
+                        continue;
+                    }
                     if (beta != (T)0) v += beta * *c;
                     *c = v;
                 }
@@ -298,6 +307,8 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     const bool w4 = w4env || sizeof(T) == 4 || ((variant == GEMM_NN_128_SS || variant == GEMM_NT_128_SS) && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
+    static const int atomic_c = getenv("PG_ATOMIC_C") ? atoi(getenv("PG_ATOMIC_C")) : 1;   // 0: read-modify-write epilogue
+    p.atomic_c = (atomic_c && sizeof(T) == 8 && p.beta == (T)1 && p.C && p.part == nullptr) ? 1 : 0;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;
