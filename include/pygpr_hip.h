@@ -76,10 +76,17 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
 /* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag is the factorisation's
  * workspace of pg_potrf_worksize(dtype, n) elements: its first n * 128 elements receive the inverses of the 128x128
  * diagonal blocks ([n/128][128][128]) that drive every later solve (pg_potrs_vec, pg_trtri ... only read that part);
- * the rest is scratch of the call: the flag words through which the resident kernels of the coupled chain hand over
- * (csrc/chainstep.hip; zeroed by every call) and the buffers of the optional recursive panel step.
- * info: 0, or j + 1 when the leading minor of order j + 1 is not positive definite (LAPACK's convention), or -1 if a bounded wait
- * inside the coupled chain expired (never seen; the factor is then undefined). */
+ * the rest (64 n/128 + 2048 elements) is scratch of the call: the flag words through which the resident kernels of the coupled
+ * chain hand over (csrc/chainstep.hip; zeroed by every call); with PG_PANEL_MODE=1 in the environment (experimental recursive
+ * panel step) its buffers follow.
+ * info: 0, or j + 1 when the leading minor of order j + 1 is not positive definite (LAPACK's convention), or -1 when a bounded
+ * wait inside the coupled chain expired: NOT a property of the matrix -- kernels of the handle's panel and rows streams did not run
+ * at the same time (seen while developing: under `rocprofv3 --pmc`, which runs one kernel at a time, before pg_create probed for
+ * that; and with a schedule variant that put the leaf and the rows on two CU-masked streams, since removed).  A and Minv are then
+ * garbage, and the handle has switched itself to the classic chain (pg_coupled_chain() == 0, pg_chain_timeouts() counts): supply
+ * the matrix again and repeat the call, or use pg_build_potrf_trtri_checked, which does that inside the call.
+ * Pointers: A (and any C operand of pg_gemm_raw / pg_syrk_tn_sub) may be any device-accessible memory; the no-return fp64 atomic
+ * epilogue of the updates is only used when hipPointerGetAttributes says plain device memory (hipMalloc / torch-ROCm). */
 long pg_potrf_worksize(int dtype, int n);   /* elements of inv_diag */
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream);
 
@@ -95,6 +102,12 @@ int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_d
 int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n, int d,
                          double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
                          void* stream);
+/* The same, BLOCKING: waits for the factorisation on `stream`, copies *info to *info_host, and if a wait of the coupled chain
+ * expired (info = -1) repeats the whole call on the classic chain before it returns -- tc.cholesky (gpr.py:69) never fails on a
+ * positive-definite matrix, and neither does this.  *info_host < 0 on return only if the repeat failed as well. */
+int pg_build_potrf_trtri_checked(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n,
+                                 int d, double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
+                                 void* stream, int* info_host);
 
 /* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
  * work: pg_potrs_vec_worksize(dtype, n) elements (2 n below n = 2048; above, also the 1024-wide diagonal block
@@ -213,9 +226,15 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
  * pg_set_coupled_chain(h, 1) re-creates the stream and probes again; pg_coupled_chain reads the state. */
 int pg_set_coupled_chain(pg_handle h, int on);
 int pg_coupled_chain(pg_handle h);
+/* Every wait of the coupled chain is bounded by wall time (default 2 s, PG_CS_SPIN_US in the environment at pg_create);
+ * microseconds < 0 makes every wait expire at once -- the deterministic test hook of the fall-back path.  pg_chain_timeouts: how
+ * many expiries this handle has seen (each one switched it to the classic chain; pg_set_coupled_chain(h, 1) probes and re-arms). */
+int pg_set_spin_budget(pg_handle h, long microseconds);
+int pg_chain_timeouts(pg_handle h);
 
 /* how many outer panels of the handle's LAST pg_potrf / pg_potrf_trtri ran on the flag-coupled chain (0: classic chain only;
- * the coupled chain needs the look-ahead schedule and a caller stream that is a real non-blocking stream) -- tests / diagnostics */
+ * the coupled chain needs the look-ahead schedule, i.e. at least three outer panels; any caller stream works, the legacy
+ * default stream included) -- tests / diagnostics */
 int pg_last_coupled_panels(pg_handle h);
 
 /* one 128x128 Cholesky leaf (factor + inverse) on its own; ablate != 0 skips phases -- timing diagnostics only */

@@ -67,6 +67,10 @@ _SIGS = {
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
     "pg_build_potrf_trtri": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _d, _vp, _l, _i, _vp, _vp, _vp, _l, _vp]),
+    "pg_build_potrf_trtri_checked": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _d, _vp, _l, _i, _vp, _vp, _vp, _l, _vp,
+                                          C.POINTER(_i)]),
+    "pg_set_spin_budget": (_i, [_vp, _l]),
+    "pg_chain_timeouts": (_i, [_vp]),
     "pg_last_coupled_panels": (_i, [_vp]),
     "pg_set_coupled_chain": (_i, [_vp, _i]),
     "pg_coupled_chain": (_i, [_vp]),

@@ -296,6 +296,36 @@ class HipOps:
     def set_coupled_chain(self, on):
         _lib.check(self.lib.pg_set_coupled_chain(self.h, int(on)), "pg_set_coupled_chain")
 
+    def set_spin_budget(self, microseconds):
+        """Wall-time bound of one wait of the coupled chain; < 0: every wait expires at once (test hook of the fall-back)."""
+        _lib.check(self.lib.pg_set_spin_budget(self.h, int(microseconds)), "pg_set_spin_budget")
+
+    def chain_timeouts(self):
+        return int(self.lib.pg_chain_timeouts(self.h))
+
+    def recover_from_timeout(self):
+        """A factorisation reported info = -1 (a wait of the coupled chain expired: include/pygpr_hip.h).  The library has
+        switched the handle to the classic chain by itself (pinned word polled at every entry point); make sure, count, and
+        tell the caller to repeat its sequence from the covariance build."""
+        torch.cuda.synchronize()
+        self.chain_timeouts()                      # polls the pinned word
+        if self.coupled_chain():
+            _lib.check(self.lib.pg_set_coupled_chain(self.h, 0), "pg_set_coupled_chain")
+        self.fallbacks = getattr(self, "fallbacks", 0) + 1
+
+    def build_factor_checked(self, spec, hp, x, a, invd, info, minv=None, jitter=JITTER):
+        """Blocking build + factor with the fall-back inside the call (pg_build_potrf_trtri_checked); returns info."""
+        passes = _passes(spec)
+        assert len(passes) == 1
+        self._chk(hp, x, a, invd, info, minv)
+        n, d = x.shape
+        out = C.c_int(0)
+        _lib.check(self.lib.pg_build_potrf_trtri_checked(
+            self.h, _code(a.dtype), C.byref(passes[0]), _p(hp), _p(x), x.stride(0), n, d, float(jitter), _p(a), a.stride(0),
+            a.shape[0], _p(invd), _p(info), _p(minv), minv.stride(0) if minv is not None else 0, self._st(), C.byref(out)),
+            "pg_build_potrf_trtri_checked")
+        return out.value
+
     def coupled_chain(self):
         return int(self.lib.pg_coupled_chain(self.h))
 

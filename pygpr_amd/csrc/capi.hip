@@ -29,6 +29,7 @@ static void release_ctx(pg_ctx* h) {
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
     free(h->pool);
+    if (h->tmo_host) (void)hipHostFree(h->tmo_host);
     delete h;
 }
 
@@ -63,12 +64,26 @@ void pg_set_error(const char* fmt, ...) {
         return -1;                                                           \
     } while (0)
 
+// A timed-out wait of the coupled chain (chainstep.h) sets the handle's pinned host word: from the next entry point on the handle
+// factorises on the classic chain (no flags, no resident kernels), so that repeating the failed call -- which is what
+// pg_build_potrf_trtri_checked and the Python layer do -- ends in a correct factor.  pg_set_coupled_chain(h, 1) probes and re-arms.
+static void poll_timeout(pg_ctx* h) {
+    if (h && h->tmo_host && *(volatile int*)h->tmo_host) {
+        *(volatile int*)h->tmo_host = 0;
+        h->coupled = 0;
+        h->timeouts += 1;
+    }
+}
+
 // pg_alpha_nlml_async leaves work on the handle's side stream; every entry point that may read its outputs (everything that
-// takes a stream except pg_lauum, which is meant to overlap with it) first makes its stream wait for that work.
+// takes a stream except pg_lauum, which is meant to overlap with it) first makes its stream wait for that work.  Only a join on
+// the stream the work was forked from retires the pending mark: a call on another stream in between waits too, but the owner's
+// next reader still does (round 2 cleared the mark at the first join of ANY stream).
 static int join_side(pg_ctx* h, void* stream) {
+    poll_timeout(h);
     if (h && h->side_pending) {
         PG_CHECK(hipStreamWaitEvent(ST(stream), h->ev[5], 0));
-        h->side_pending = 0;
+        if (ST(stream) == h->side_owner) h->side_pending = 0;
     }
     return 0;
 }
@@ -77,6 +92,23 @@ static int join_side(pg_ctx* h, void* stream) {
         int _j = join_side((h), (stream));      \
         if (_j) return _j;                      \
     } while (0)
+
+// The beta == 1 epilogue of the GEMM core adds into C with no-return fp64 atomics performed at the memory side.  On fine-grained,
+// host-pinned or managed allocations such atomics may be dropped or crawl, so the entry points that take a caller-owned C check
+// the pointer once and keep the read-modify-write epilogue for anything that is not plain device memory.
+static int plain_device_memory(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a.type == hipMemoryTypeDevice && !a.isManaged;
+}
+struct AtomicGuard {
+    pg_ctx* h;
+    AtomicGuard(pg_ctx* h_, const void* c) : h(h_) { if (h) h->no_atomic_c = plain_device_memory(c) ? 0 : 1; }
+    ~AtomicGuard() { if (h) h->no_atomic_c = 0; }
+};
 
 template <typename T>
 static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alpha, const void* A, long lda, const void* B,
@@ -95,11 +127,11 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     if (rs && rs[0] == 'u' && h->upd) on = h->upd;
     if (rs && rs[0] == 'b' && h->bg) on = h->bg;
     if (on == ST(stream)) return pg_gemm<T>(h, on, variant, p);
-    PG_CHECK(hipEventRecord(h->ev[4], ST(stream)));
-    PG_CHECK(hipStreamWaitEvent(on, h->ev[4], 0));
+    PG_CHECK(hipEventRecord(h->ev[2], ST(stream)));      // (ev[4] / ev[5] belong to pg_alpha_nlml_async's side-stream fork)
+    PG_CHECK(hipStreamWaitEvent(on, h->ev[2], 0));
     const int rc = pg_gemm<T>(h, on, variant, p);
-    PG_CHECK(hipEventRecord(h->ev[5], on));
-    PG_CHECK(hipStreamWaitEvent(ST(stream), h->ev[5], 0));
+    PG_CHECK(hipEventRecord(h->ev[3], on));
+    PG_CHECK(hipStreamWaitEvent(ST(stream), h->ev[3], 0));
     return rc;
 }
 
@@ -220,6 +252,19 @@ int pg_create(pg_handle* h) {
         }
     }
     c->coupled = (c->rows && probe_concurrent_queues(c)) ? 1 : 0;
+    {   // pinned word through which a timed-out wait of the coupled chain reaches the host (poll_timeout), and the wait budget
+        c->tmo_host = nullptr;
+        c->tmo_dev = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->tmo_host), 64, hipHostMallocMapped) == hipSuccess) {
+            c->tmo_host[0] = 0;
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->tmo_dev), c->tmo_host, 0) != hipSuccess) c->tmo_dev = nullptr;
+        }
+        (void)hipGetLastError();
+        const char* e = getenv("PG_CS_SPIN_US");
+        const long long us = e ? atoll(e) : 2000000LL;      // 2 s per wait: three orders of magnitude above any step of the chain
+        c->spin_ticks = us < 0 ? -1 : std::max<long long>(us, 1) * 100;
+        c->timeouts = 0;
+    }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
@@ -293,6 +338,7 @@ int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const d
     if (check_spec(spec, __func__, true)) return -1;
     NEED(n >= 0 && n_pad >= n && lda >= n_pad, "inconsistent sizes");
     NEED(lda % (dtype == PG_F64 ? 2 : 4) == 0, "lda must keep rows 16-byte aligned");
+    AtomicGuard ag(h, A);
     DISPATCH(dtype, build_potrf_t<double>(h, ST(stream), spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm),
              build_potrf_t<float>(h, ST(stream), spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm));
 }
@@ -302,6 +348,7 @@ long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
     JOIN(h, stream);
     NEED(h && A && inv_diag && info, "null pointer");
+    AtomicGuard ag(h, A);
     NEED(lda >= n, "lda < n");
     DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, nullptr, 0),
              pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info, nullptr, 0));
@@ -312,6 +359,7 @@ int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_d
     JOIN(h, stream);
     NEED(h && A && inv_diag && info && Minv, "null pointer");
     NEED(lda >= n && ldm >= n && A != Minv, "bad leading dimension / aliasing");
+    AtomicGuard ag(h, A);
     DISPATCH(dtype, pg_potrf_t<double>(h, ST(stream), n, (double*)A, lda, (double*)inv_diag, info, (double*)Minv, ldm),
              pg_potrf_t<float>(h, ST(stream), n, (float*)A, lda, (float*)inv_diag, info, (float*)Minv, ldm));
 }
@@ -451,6 +499,7 @@ int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, 
                    void* stream) {
     JOIN(h, stream);
     NEED(h && V && C, "null pointer");
+    AtomicGuard ag(h, C);
     DISPATCH(dtype, pg_syrk_tn_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)V, ldv, (double*)C, ldc, lower_only),
              pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc, lower_only));
 }
@@ -575,6 +624,35 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
     return 0;
 }
 
+int pg_set_spin_budget(pg_handle h, long microseconds) {
+    NEED(h, "null handle");
+    h->spin_ticks = microseconds < 0 ? -1 : std::max<long long>(microseconds, 1) * 100;
+    return 0;
+}
+int pg_chain_timeouts(pg_handle h) {
+    if (!h) return -1;
+    poll_timeout(h);
+    return h->timeouts;
+}
+
+// Blocking form of pg_build_potrf_trtri: waits for the factorisation and, when a wait of the coupled chain expired (info = -1),
+// repeats the whole call -- covariance build included, the first attempt's A is garbage -- on the classic chain before it returns.
+int pg_build_potrf_trtri_checked(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx, int n,
+                                 int d, double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
+                                 void* stream, int* info_host) {
+    NEED(info_host, "null pointer");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int rc = pg_build_potrf_trtri(h, dtype, spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm, stream);
+        if (rc) return rc;
+        PG_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, ST(stream)));
+        PG_CHECK(hipStreamSynchronize(ST(stream)));
+        if (*info_host >= 0) return 0;
+        poll_timeout(h);
+        h->coupled = 0;        // whatever the pinned word said: the repeat must not take the coupled chain
+    }
+    return 0;
+}
+
 int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream) {
     JOIN(h, stream);
     NEED(h && A && info, "null pointer");
@@ -590,6 +668,7 @@ int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double
              variant == GEMM_TT_128 || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_NT_32x64 ||
              variant == GEMM_NT_32x128 || variant == GEMM_TT_64 || variant == GEMM_NT_32x32,
          "variant not exposed");
+    AtomicGuard ag(h, C);
     DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),
              gemm_raw_t<float>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream));
 }

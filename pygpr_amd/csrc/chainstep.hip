@@ -28,25 +28,12 @@
 #define CS_KC 32
 #define CS_CLD (CS_KC + 2)
 #define CS_XLD (NB + 2)
-#define CS_SPIN_LIMIT (1u << 22)     // x (s_sleep + one L2 round trip) = a few seconds
 
-#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-
-__device__ __forceinline__ bool cs_spin_ge(int* flag, int want, int* tmo) {   // ONE lane
-    for (unsigned it = 0;; ++it) {
-        if (__hip_atomic_load(flag, RLX_AGENT) >= want) return true;
-        if ((it & 31u) == 31u && __hip_atomic_load(tmo, RLX_AGENT) != 0) return false;
-        if (it > CS_SPIN_LIMIT) {
-            __hip_atomic_store(tmo, 1, RLX_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
+#define RLX_AGENT PG_RLX_AGENT
 
 // Whole workgroup: wait until *flag >= want, then make the publisher's bytes loadable (one lane's agent-scope acquire drops this
 // CU's L1 lines; its wait holds the barrier for the invalidate).
-__device__ __forceinline__ void cs_wg_wait(int* flag, int want, int* tmo, int* info) {
+__device__ __forceinline__ void cs_wg_wait(int* flag, int want, const CsWait& tmo, int* info) {
     if (threadIdx.x == 0) {
         if (!cs_spin_ge(flag, want, tmo)) atomicCAS(info, 0, -1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -79,7 +66,7 @@ template <> __device__ __forceinline__ float ld_wt<float>(const float* p) {
 }
 
 // Whole workgroup: wait for *flag >= want WITHOUT an acquire: for workgroups whose every later load of handed-off bytes is ld_wt
-__device__ __forceinline__ void cs_wg_wait_wt(int* flag, int want, int* tmo, int* info) {
+__device__ __forceinline__ void cs_wg_wait_wt(int* flag, int want, const CsWait& tmo, int* info) {
     if (threadIdx.x == 0) {
         if (!cs_spin_ge(flag, want, tmo)) atomicCAS(info, 0, -1);
     }
@@ -222,7 +209,7 @@ __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T
 template <typename T, int RG>
 __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, long lda, int row0, int o0, int k0, bool has_next,
                                              bool crit, const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next, int ncrit,
-                                             int* tmo, int* info, int direct, long long* tlog) {
+                                             const CsWait& tmo, int* info, int direct, long long* tlog) {
     constexpr int ROWS = 16 * RG, NJ = RG, WC = 16 * NJ;
 #define TL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     constexpr int VE = 16 / sizeof(T);
@@ -320,7 +307,7 @@ __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, 
 template <typename T>
 __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
                                                                const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
-                                                               int* tmo, int* info, int direct, long long* tlog) {
+                                                               CsWait tmo, int* info, int direct, long long* tlog) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int w = blockIdx.x;
     if (w < CS_NCRIT)
@@ -335,7 +322,7 @@ __global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(fla
 
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, int* tmo, int* info) {
+               int* diag_next, const CsWait& tmo, int* info) {
     const int m = n - k0 - NB;
     if (m <= 0 || m % NB) { pg_set_error("pg_rowstep: %d rows below the tile", m); return -2; }
     const size_t lds = (size_t)(32 * CS_XLD + 32 * CS_CLD + NB * CS_CLD) * sizeof(T);
@@ -348,12 +335,12 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
     static const int direct = getenv("PG_CS_K128") ? atoi(getenv("PG_CS_K128")) : 1;
     hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
-                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (k0 / NB) : nullptr);
+                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (k0 / NB) : nullptr);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, int*, int*);
-template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, int*, int*);
+template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*);
+template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*);
 
 int pg_flagset(hipStream_t st, int* flag, int value) {
     hipLaunchKernelGGL(pg_flagset_kernel, dim3(1), dim3(1), 0, st, flag, value);

@@ -30,6 +30,12 @@ struct pg_ctx {
     int last_coupled;         // panels the last factorisation ran on the flag-coupled chain (chainstep.hip); tests / diagnostics
     int panel_mode;           // how the rows below an outer panel ride its 128-column steps (linalg.hip, PG_PANEL_MODE)
     int side_pending;         // side-stream work (pg_alpha_nlml_async) that the next reader of its outputs must wait for: ev[5]
+    hipStream_t side_owner;   // the caller stream that work was forked from: only a join on THAT stream clears side_pending
+    int* tmo_host;            // pinned host word a timed-out wait of the coupled chain sets (chainstep.h); polled at every entry point
+    int* tmo_dev;             // its device address
+    long long spin_ticks;     // budget of one wait of the coupled chain in 10 ns ticks (< 0: forced expiry, test hook)
+    int timeouts;             // coupled-chain time-outs seen on this handle (each switched the handle to the classic chain)
+    int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;
     double prof_ms;

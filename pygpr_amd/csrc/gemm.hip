@@ -308,7 +308,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
     static const int atomic_c = getenv("PG_ATOMIC_C") ? atoi(getenv("PG_ATOMIC_C")) : 1;   // 0: read-modify-write epilogue
-    p.atomic_c = (atomic_c && sizeof(T) == 8 && p.beta == (T)1 && p.C && p.part == nullptr) ? 1 : 0;
+    p.atomic_c = (atomic_c && !(ctx && ctx->no_atomic_c) && sizeof(T) == 8 && p.beta == (T)1 && p.C && p.part == nullptr) ? 1 : 0;
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;

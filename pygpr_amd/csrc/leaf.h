@@ -5,5 +5,6 @@
 // ablate != 0 skips phases (timing diagnostics only: bit 0 factor loop, 1 inverse, 3 diagonal step).
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate = 0);
 // The same leaf as one half of the flag-coupled chain (chainstep.hip): waits for *ready >= want, factors, sets *done.
+struct CsWait;
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
-                                       int* tmo);
+                                       const CsWait& tmo);

@@ -18,6 +18,7 @@
 //     touches; after the loop only Dinv[7] and block row 7 are left.
 // LDS: S[128][130] + 8 x [16][18] diagonal inverses, all in the dynamic region.
 #include "leaf.h"
+#include "chainstep.h"
 #include <cstdlib>
 
 #define NB 128
@@ -520,20 +521,11 @@ __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long l
 // *done is set on every path (bad pivot, earlier failure, timeout): the rows below wait for it.
 template <typename T, bool WT>
 __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
-                                                        int col0, int* ready, int want, int* done, int* tmo, long long* tlog) {
+                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
-        for (unsigned it = 0;; ++it) {
-            if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-            if ((it & 31u) == 31u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (it > (1u << 22)) {
-                __hip_atomic_store(tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicCAS(info, 0, -1);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
+        if (!cs_spin_ge(ready, want, tmo)) atomicCAS(info, 0, -1);
         if (!WT) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,7 +548,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
 }
 
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
-                                       int* tmo) {
+                                       const CsWait& tmo) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -568,14 +560,14 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     }
     static const int wt = getenv("PG_CS_LEAF_WT") ? atoi(getenv("PG_CS_LEAF_WT")) : 1;
     if (wt) hipLaunchKernelGGL((pg_leaf2s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
-                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (col0 / NB) : nullptr);
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (col0 / NB) : nullptr);
     else hipLaunchKernelGGL((pg_leaf2s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
-                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo) + 512 + 16 * (col0 / NB) : nullptr);
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (col0 / NB) : nullptr);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, int*);
-template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, int*);
+template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&);
+template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&);
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;

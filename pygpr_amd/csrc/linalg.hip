@@ -378,12 +378,20 @@ template <typename T> static GemmP<T> gp0() {
     return p;
 }
 
-// inv_diag [n/128][128][128], then the work area of the panel step: W = inverse of the current outer panel's triangular
-// factor (at most 2048 x 2048) and Xs = the panel's solved rows before they are copied back (n x at most 2048).
+// inv_diag [n/128][128][128], then the flag words of the coupled chain (3 n/128 + 1 ints, and the in-kernel time log when
+// PG_CS_TLOG is set), then -- only in the experimental recursive-panel mode (PG_PANEL_MODE=1) -- the work area of the panel step:
+// W = inverse of the current outer panel's triangular factor (at most 2048 x 2048) and Xs = the panel's solved rows before they
+// are copied back (n x at most 2048).  The default mode's workspace is n * 128 + 64 n/128 + 2048 elements (round 2 always
+// carried W and Xs: +300 MB at n = 16384, 35x the default need of a 2048-point expert).
 #define NBO_MAX 2048
+static int pg_panel_mode_env() {
+    static const int v = getenv("PG_PANEL_MODE") ? atoi(getenv("PG_PANEL_MODE")) : 0;
+    return v;
+}
+static long pg_flag_elems(int n) { return 64L * (n / NB) + 2048; }   // elements of T (>= 4 bytes each)
 long pg_potrf_worksize_impl(int n) {
     const long w = std::min<long>(n, NBO_MAX);
-    return (long)n * NB + w * w + (long)n * w;
+    return (long)n * NB + pg_flag_elems(n) + (pg_panel_mode_env() == 1 ? w * w + (long)n * w : 0);
 }
 
 template <typename T>
@@ -533,8 +541,9 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // (below n = 5120 the cross-stream split costs more than the overlap returns: 3.66 vs 3.79 ms at n = 4096)
     const int split = (Minv && la && ctx->bg && n / NBO >= 4 && n >= 5120) ? ((n + NBO - 1) / NBO / 2) * NBO : 0;
     const long NBW = std::min<long>(n, NBO_MAX);
-    T* Wt = invD + (long)n * NB;          // inverse of the current panel's triangular factor, leading dimension = panel width
-    T* Xs = Wt + NBW * NBW;               // the panel's solved rows (out of place), leading dimension = panel width
+    T* flagw = invD + (long)n * NB;       // flag words of the coupled chain
+    T* Wt = flagw + pg_flag_elems(n);     // (PG_PANEL_MODE=1 only) inverse of the current panel's triangular factor, leading dimension = panel width
+    T* Xs = Wt + NBW * NBW;               // (PG_PANEL_MODE=1 only) the panel's solved rows (out of place), leading dimension = panel width
     const bool coupled = la && want_cp;
     int o_s = npan;                             // first coupled panel
     if (coupled)
@@ -542,10 +551,11 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             if (n - pb[o] <= sync_rows) { o_s = o; break; }
     ctx->last_coupled = npan - o_s;
     const int nblk = n / NB;
-    int* f_diag = reinterpret_cast<int*>(Xs);   // [nblk] workgroups that have published tile (b, b);  the work area is ours
+    int* f_diag = reinterpret_cast<int*>(flagw);   // [nblk] workgroups that have published tile (b, b)
     int* f_done = f_diag + nblk;                // [nblk] leaf b has stored L_bb and its inverse
     int* f_brow = f_done + nblk;                // [nblk] workgroups that have published X[block row b+1, block column b]
     int* f_tmo = f_brow + nblk;                 // sticky time-out word
+    const CsWait cw = {f_tmo, ctx->tmo_dev, ctx->spin_ticks};
     if (o_s < npan) {
         PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((3 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
     }
@@ -564,7 +574,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             for (int k0 = o0; k0 < oend; k0 += NB) {
                 const int kb = k0 / NB;
                 T* inv = invD + (long)kb * NB * NB;
-                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, f_tmo))) return rc;
+                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw))) return rc;
                 if (n - k0 - NB <= 0) break;
                 const int c = k0 + NB;                       // the block column this step brings up to date
                 const int oc = c < oend ? o : o + 1;         // its panel
@@ -577,11 +587,11 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
-                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, f_tmo, info)))
+                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info)))
                     return rc;
             }
         }
-        const int mode = (oend < n) ? ctx->panel_mode : 0;
+        const int mode = (oend < n && pg_panel_mode_env() == 1) ? ctx->panel_mode : 0;
         const bool v2 = mode == 1;
         const int tri_end = v2 ? oend : n;     // last row the panel stream's 128-column steps touch
         for (int k0 = o0; k0 < oend && !cp; k0 += NB) {
@@ -810,6 +820,7 @@ int pg_alpha_nlml_async_t(pg_ctx* ctx, hipStream_t st, int n_real, int n, const 
     if (side != st) {
         PG_CHECK(hipEventRecord(ctx->ev[5], side));
         ctx->side_pending = 1;
+        ctx->side_owner = st;
     }
     return 0;
 }

@@ -24,13 +24,17 @@ from .covar import Covar, layout, spec_of
 _CHUNK = 8192  # test points per device batch
 
 
+class ChainTimeout(torch.linalg.LinAlgError):
+    """info = -1: a bounded wait inside the factorisation's flag-coupled chain expired -- kernels of the library's streams did
+    not run concurrently (include/pygpr_hip.h).  Not a property of the matrix.  Every caller in this package answers it by
+    repeating the evaluation on the classic chain (`HipOps.recover_from_timeout`); the exception only escapes if the repeat
+    fails too.  A LinAlgError subclass so that the committee's status-word paths (gr_bcm.py) treat it like any failed expert."""
+
+
 def _lin_alg_error(info: int, note: str = ""):
     if int(info) < 0:
-        # not a property of the matrix: a bounded wait inside the factorisation's flag-coupled chain expired, i.e. kernels of the
-        # library's streams did not run concurrently (pg_create probes for that; include/pygpr_hip.h: pg_set_coupled_chain)
-        err = RuntimeError("pygpr_amd: the factorisation's coupled chain timed out (info = %d): kernels of different streams do "
-                           "not run concurrently in this environment; call pygpr_amd._ops.get_ops().set_coupled_chain(0) or "
-                           "set PG_SYNC_ROWS=0%s" % (int(info), note))
+        err = ChainTimeout("pygpr_amd: the factorisation's coupled chain timed out twice (info = %d): kernels of different "
+                           "streams do not run concurrently in this environment%s" % (int(info), note))
         err.pg_info = int(info)
         return err
     err = torch.linalg.LinAlgError(
@@ -38,6 +42,19 @@ def _lin_alg_error(info: int, note: str = ""):
         "(the leading minor of order %d is not positive-definite)%s." % (info, note))
     err.pg_info = int(info)
     return err
+
+
+def _checked(enqueue, infos):
+    """Run `enqueue()` (device work that ends in the factorisation status words `infos()` reads after one sync).  info < 0 is
+    the coupled chain's time-out: switch the handle to the classic chain and repeat ONCE from the start -- tc.cholesky
+    (gpr.py:69) never fails on a positive-definite matrix.  Returns the final status words."""
+    enqueue()
+    vals = [int(v) for v in infos()]
+    if any(v < 0 for v in vals):
+        get_ops().recover_from_timeout()
+        enqueue()
+        vals = [int(v) for v in infos()]
+    return vals
 
 
 class GPR:
@@ -182,34 +199,37 @@ class Exact_GP(GPR):
 
     # ---- the path ---------------------------------------------------------------------------
     def update(self) -> None:
+        experts = self._device_experts()      # first: an in-place edit of x / y (version bump) marks the model dirty here
         if self.need_upd:
             ops = get_ops()
-            experts = self._device_experts()
             hp_rows = self._hp_rows()
             spec, nhp = spec_of(self.cov, self._x.shape[-1])
             assert hp_rows.shape[-1] == nhp
-            for b, e in enumerate(experts):
-                e.hp = ops.to_device(hp_rows[b % hp_rows.shape[0]], torch.float64)
-                if e.chol is None:
-                    e.chol = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
-                    e.invd = ops.potrf_workspace(e.n_pad, self.dtype)
-                    e.alpha = ops.empty(e.n_pad, dtype=self.dtype)
-                    e.info = torch.zeros(1, dtype=torch.int32, device=ops.device)
-                if self.eager_inverse:
-                    if e.minv is None:
-                        e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
-                        e.work = ops.empty((e.n_pad // 256 + 1) * e.n_pad, dtype=self.dtype)
-                    ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info, e.minv)
-                    u = e.work[: e.n_pad]
-                    ops.trmv(e.minv, e.y, u, 0)
-                    ops.trmv(e.minv, u, e.alpha, 1, e.work[e.n_pad:])
-                    e.minv_valid = True
-                else:
-                    e.minv_valid = False
-                    ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info)
-                    ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
-            for e in experts:   # one sync point after everything is enqueued
-                info = int(e.info.item())
+
+            def enqueue():
+                for b, e in enumerate(experts):
+                    e.hp = ops.to_device(hp_rows[b % hp_rows.shape[0]], torch.float64)
+                    if e.chol is None:
+                        e.chol = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+                        e.invd = ops.potrf_workspace(e.n_pad, self.dtype)
+                        e.alpha = ops.empty(e.n_pad, dtype=self.dtype)
+                        e.info = torch.zeros(1, dtype=torch.int32, device=ops.device)
+                    if self.eager_inverse:
+                        if e.minv is None:
+                            e.minv = ops.empty(e.n_pad, e.n_pad, dtype=self.dtype)
+                            e.work = ops.empty((e.n_pad // 256 + 1) * e.n_pad, dtype=self.dtype)
+                        ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info, e.minv)
+                        u = e.work[: e.n_pad]
+                        ops.trmv(e.minv, e.y, u, 0)
+                        ops.trmv(e.minv, u, e.alpha, 1, e.work[e.n_pad:])
+                        e.minv_valid = True
+                    else:
+                        e.minv_valid = False
+                        ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info)
+                        ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
+
+            # one sync point after everything is enqueued; a timed-out coupled chain repeats the lot on the classic chain
+            for info in _checked(enqueue, lambda: torch.cat([e.info for e in experts]).tolist()):
                 if info:
                     raise _lin_alg_error(info)
             self.need_upd = False

@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 from ._ops import get_ops, pad_to
-from .gpr import GPR, Exact_GP, _lin_alg_error
+from .gpr import GPR, Exact_GP, _checked, _lin_alg_error
 from .loss import MLE, Loss
 
 
@@ -57,6 +57,17 @@ def _all_reduce_sum(t, group=None):
 
 def _all_reduce_max(t, group=None):
     return _all_reduce(t, dist.ReduceOp.MAX, group)
+
+
+def _raise_if_any_failed(words, rank, own):
+    """words[r] = rank r's factorisation status after the sum (0 = fine).  Every rank raises the same way: its own status if
+    it failed, otherwise the lowest failing rank's, named."""
+    if own:
+        raise _lin_alg_error(own)
+    for r, w in enumerate(words):
+        st = int(round(float(w)))
+        if st:
+            raise _lin_alg_error(st, " (reported by rank %d of the committee)" % r)
 
 
 class GRBCM(GPR):
@@ -114,23 +125,21 @@ class GRBCM(GPR):
 
     # ---- aggregation ------------------------------------------------------------------------
     def _reduce_terms(self, flat, m, status=0):
-        """The ONE all-reduce of a test batch: [3, m] aggregation terms + one status word, so that a factorisation
-        that failed on one rank (LinAlgError before it could join the collective) fails on every rank instead of
-        leaving the others blocked in the all-reduce."""
+        """The ONE all-reduce of a test batch: [3, m] aggregation terms + one status word PER RANK (rank r writes word r, so
+        the sum keeps every rank's own value: round 2 summed them into one word and two failing ranks reported a meaningless
+        minor), so that a factorisation that failed on one rank (LinAlgError before it could join the collective) fails on
+        every rank instead of leaving the others blocked in the all-reduce."""
         if status:
-            flat[3 * m:] = float(status)
+            flat[3 * m + self.rank] = float(status)
         _all_reduce_sum(flat, self.group)
-        st = int(round(float(flat[3 * m].item())))
-        if st:
-            raise _lin_alg_error(status if status else st,
-                                 "" if status else " (reported by another rank of the committee)")
+        _raise_if_any_failed(flat[3 * m: 3 * m + self.world].tolist(), self.rank, status)
 
     def _aggregate_device(self, mean_g, var_g, means_l, vars_l):
         """Device tensors in, device tensors out.  beta/prec rows: [global, owned local experts...]."""
         ops = get_ops()
         m = mean_g.numel()
         nloc = len(means_l)
-        flat = ops.zeros(3 * m + 1, dtype=torch.float64)
+        flat = ops.zeros(3 * m + self.world, dtype=torch.float64)
         sums = flat[: 3 * m].view(3, m)
         beta = ops.empty(nloc + 1, m, dtype=torch.float64)
         prec = ops.empty(nloc + 1, m, dtype=torch.float64)
@@ -165,31 +174,49 @@ class GRBCM(GPR):
         var_g = cov_g.diagonal().contiguous()
         vars_l = [c.diagonal().contiguous() for c in covs_l]
         self._aggregate_device(mean_g, var_g, means_l, vars_l)       # fills self._sums, beta, prec
-        acc = None
-        infos = []
-        for c, cov in enumerate(covs_l):
-            pc, info = ops.spd_inverse_lower(self._padded_spd(cov))
-            infos.append(info)
+        state = {}
+
+        def enqueue():
+            acc = None
+            infos = []
+            for c, cov_c in enumerate(covs_l):
+                pc, info = ops.spd_inverse_lower(self._padded_spd(cov_c))
+                infos.append(info)
+                if acc is None:
+                    acc = ops.empty(pc.shape[0], pc.shape[0], dtype=pc.dtype)
+                ops.grbcm_weighted_prec(pc, self.beta[c + 1].contiguous(), acc, m, c > 0)
             if acc is None:
-                acc = ops.empty(pc.shape[0], pc.shape[0], dtype=pc.dtype)
-            ops.grbcm_weighted_prec(pc, self.beta[c + 1].contiguous(), acc, m, c > 0)
-        if acc is None:
-            acc = self._padded_spd(torch.zeros(m, m, dtype=cov_g.dtype, device=cov_g.device))
-            acc.diagonal()[:m] = 0.0
+                acc = self._padded_spd(torch.zeros(m, m, dtype=cov_g.dtype, device=cov_g.device))
+                acc.diagonal()[:m] = 0.0
+            state["acc"], state["infos"] = acc, infos
+
+        def local_infos():
+            return [int(i.item()) for i in state["infos"]]
+
+        # the m x m inverses of the owned experts are rank-local: a timed-out coupled chain is repaired here, before the collective
+        local = _checked(enqueue, local_infos)
+        acc = state["acc"]
         if self.distributed:
             mp = acc.shape[0]
             if mp > m and self.world > 1:          # keep the padding's unit diagonal a unit after the sum
                 acc.diagonal()[m:] = 1.0 / self.world
             _all_reduce_sum(acc, self.group)
-        p0, info = ops.spd_inverse_lower(self._padded_spd(cov_g))
-        infos.append(info)
-        ops.grbcm_weighted_prec(p0, self.beta[0].contiguous(), acc, m, True)
-        cov, info = ops.spd_inverse_lower(acc)
-        infos.append(info)
-        bad = max(int(i.item()) for i in infos)
-        if self.distributed:            # every rank raises together (the m x m inverses above are rank-local)
-            t = torch.tensor([float(bad)], dtype=torch.float64, device=acc.device)
-            bad = int(round(float(_all_reduce_max(t, self.group).item())))
+
+        def enqueue2():
+            a2 = acc.clone()
+            p0, info0 = ops.spd_inverse_lower(self._padded_spd(cov_g))
+            ops.grbcm_weighted_prec(p0, self.beta[0].contiguous(), a2, m, True)
+            cov, info1 = ops.spd_inverse_lower(a2)
+            state["cov"], state["infos2"] = cov, [info0, info1]
+
+        tail = _checked(enqueue2, lambda: [int(i.item()) for i in state["infos2"]])
+        cov = state["cov"]
+        bad = next((v for v in local + tail if v), 0)
+        if self.distributed:            # every rank raises together: one status word per rank
+            t = ops.zeros(self.world, dtype=torch.float64)
+            t[self.rank] = float(bad)
+            _all_reduce_sum(t, self.group)
+            _raise_if_any_failed(t.tolist(), self.rank, bad)
         if bad:
             raise _lin_alg_error(bad)
         ops.symmetrize(cov, cov.shape[0])
@@ -230,7 +257,7 @@ class GRBCM(GPR):
             if not self.distributed:
                 raise
             m = xsd.shape[0]                # join the batch's all-reduce with the status word set, then raise
-            self._reduce_terms(ops.zeros(3 * m + 1, dtype=torch.float64), m, getattr(err, "pg_info", 1) or 1)
+            self._reduce_terms(ops.zeros(3 * m + self.world, dtype=torch.float64), m, getattr(err, "pg_info", 1) or 1)
             raise
         if want == "diag":
             mean, out = self._aggregate_device(mg[0], vg[0], ml, vl)
@@ -243,8 +270,8 @@ class GRBCM(GPR):
 
 class GRBCM_MLE(Loss):
     """Shared-hyper-parameter objective sum_c NLML_c over the local experts of a GRBCM, with its
-    gradient: per-expert evaluations are independent (loss.py path); ranks exchange one [1 + nhp]
-    all-reduce.  Works with CG / get_learn_rate like any Loss."""
+    gradient: per-expert evaluations are independent (loss.py path); ranks exchange one all-reduce of
+    [1 + nhp] + one status word per rank.  Works with CG / get_learn_rate like any Loss."""
 
     def __init__(self, model: GRBCM) -> None:
         super().__init__(model)
@@ -275,10 +302,12 @@ class GRBCM_MLE(Loss):
         """[sum_c NLML_c, gradient, status]: the status word rides in the same all-reduce, so that a non-PD expert on
         one rank raises LinAlgError on every rank instead of leaving the others blocked in the collective."""
         nhp = np.asarray(params).shape[-1]
-        vec = np.zeros(2 + nhp)
+        g = self.model
+        vec = np.zeros(1 + nhp + g.world)          # [sum NLML, gradient, one status word per rank]
         failed = None
+        own = 0
         if self._mle is not None:
-            nloc = self.model.hi - self.model.lo
+            nloc = g.hi - g.lo
             rows = np.broadcast_to(np.asarray(params, dtype=np.float64), (nloc, nhp))
             try:
                 loss, grad = self._mle._evaluate(rows, want_grad)
@@ -286,16 +315,16 @@ class GRBCM_MLE(Loss):
                 if want_grad:
                     vec[1: 1 + nhp] = np.sum(np.atleast_2d(grad), axis=0)
             except torch.linalg.LinAlgError as err:
-                if not self.model.distributed:
+                if not g.distributed:
                     raise
                 failed = err
+                own = int(getattr(err, "pg_info", 1) or 1)
                 vec[:] = 0.0
-                vec[1 + nhp] = float(getattr(err, "pg_info", 1) or 1)
+                vec[1 + nhp + g.rank] = float(own)
         vec = self._reduce(vec)
         if failed is not None:
             raise failed
-        if vec[1 + nhp] != 0.0:
-            raise _lin_alg_error(int(round(vec[1 + nhp])), " (reported by another rank of the committee)")
+        _raise_if_any_failed(vec[1 + nhp:].tolist(), g.rank, 0)
         return vec[: 1 + nhp]
 
     def loss(self, params):

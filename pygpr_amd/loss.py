@@ -17,7 +17,7 @@ from numpy import ndarray
 
 from ._ops import get_ops
 from .covar import layout, spec_of
-from .gpr import GPR, _lin_alg_error
+from .gpr import GPR, _checked, _lin_alg_error
 
 
 class Loss():
@@ -109,25 +109,32 @@ class MLE(Loss):
             if want_grad and buf["m"] is None:
                 buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
             m = buf["m"]
-            if reuse_factor and nb == 1:
-                # `a` still holds the factor and buf["alpha"] the weights of the loss-only evaluation at these parameters
-                ops.trtri(a, buf["invd"], m)
-                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
-                ops.lauum(m, a)
-                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
-            elif want_grad:
-                ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"], m)   # covariance build + Cholesky + L^-1 in one call
-                # alpha = L^-T (L^-1 y) and the NLML value on the library's side stream, beside K^-1 = L^-T L^-1 (lower, over a)
-                ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, buf["val"])
-                ops.lauum(m, a)
-                ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])   # waits for the side stream
-                out[0:1].copy_(buf["val"][0:1])
-            else:
-                ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"])
-                ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
-                ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
-            res = out.cpu().numpy()                                   # the one sync + transfer
-            info = int(buf["info"].item())
+            res = [None]
+
+            def enqueue():
+                if reuse_factor and nb == 1:
+                    # `a` still holds the factor and buf["alpha"] the weights of the loss-only evaluation at these parameters
+                    ops.trtri(a, buf["invd"], m)
+                    ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
+                    ops.lauum(m, a)
+                    ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
+                elif want_grad:
+                    ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"], m)   # covariance build + Cholesky + L^-1 in one call
+                    # alpha = L^-T (L^-1 y) and the NLML value on the library's side stream, beside K^-1 = L^-T L^-1 (lower, over a)
+                    ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, buf["val"])
+                    ops.lauum(m, a)
+                    ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])   # waits for the side stream
+                    out[0:1].copy_(buf["val"][0:1])
+                else:
+                    ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"])
+                    ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
+                    ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
+                res[0] = out.cpu().numpy()                              # the one sync + transfer
+
+            # (a timed-out coupled chain -- info = -1 -- repeats the evaluation on the classic chain; the re-used factor of a
+            # loss-only evaluation was checked when it was made, so that branch cannot time out)
+            info = _checked(enqueue, lambda: [buf["info"].item()])[0]
+            res = res[0]
             if info:
                 raise _lin_alg_error(info)
             losses[b] = res[0]

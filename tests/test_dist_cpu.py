@@ -1,5 +1,5 @@
-"""world_size-2 gloo run of the multi-GPU path's host side: experts sharded over ranks, ONE all-reduce of the
-[3, m] aggregation buffer per test batch and ONE of [1 + nhp] per shared-hp evaluation.  Device ops are the
+"""gloo runs of the multi-GPU path's host side: experts sharded over ranks, ONE all-reduce of the [3, m] aggregation
+buffer (+ one status word per rank) per test batch and ONE of [1 + nhp] (+ one status word per rank) per shared-hp evaluation.  Device ops are the
 oracle-backed test double (tests/oracle_ops.py); the result must equal the single-process golden output."""
 import os
 import sys
@@ -57,7 +57,7 @@ def _worker(rank, world, port, out_dir):
             call()
             raised.append(0)
         except torch.linalg.LinAlgError as err:
-            raised.append(2 if "another rank" in str(err) else 1)
+            raised.append(2 if "reported by rank %d" % (world - 1) in str(err) else 1)
     res["raised"] = np.array(raised)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()

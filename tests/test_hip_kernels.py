@@ -791,3 +791,65 @@ def test_build_folded_into_the_factorisation(ops, n, with_inv):
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
     k = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
     np.testing.assert_allclose(outs[1][0][:n, :n], np.linalg.cholesky(k), atol=1e-10)
+
+
+# ---- the coupled chain's time-out ends in a correct factor (tc.cholesky, PyGPR/gpr.py:69, never fails on a PD matrix) ----------
+@pytest.fixture
+def forced_timeout(ops):
+    """Every wait of the coupled chain expires at once (pg_set_spin_budget(h, -1)): the deterministic stand-in for an environment
+    whose queues do not run concurrently.  The chain is re-armed afterwards whatever the test did."""
+    assert ops.coupled_chain() == 1
+    ops.set_spin_budget(-1)
+    yield
+    ops.set_spin_budget(2_000_000)
+    ops.set_coupled_chain(1)
+    assert ops.coupled_chain() == 1
+
+
+@pytest.mark.gpu
+def test_coupled_chain_timeout_reports_and_switches_to_the_classic_chain(ops, forced_timeout):
+    """C ABI, asynchronous entry point: info = -1, the handle has switched itself off the coupled chain by the next entry point
+    (pg_coupled_chain() == 0, pg_chain_timeouts() counted it), and repeating the call gives LAPACK's factor."""
+    n = 3072
+    a = spd(n, np.random.default_rng(23))
+    before = ops.chain_timeouts()
+    _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+    assert coupled == 6 and info == -1
+    assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0
+    ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
+    assert info == 0 and coupled == 0
+    np.testing.assert_allclose(np.tril(host(ad)), np.linalg.cholesky(a), atol=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_inv", [False, True])
+def test_build_potrf_trtri_checked_falls_back_inside_the_call(ops, forced_timeout, with_inv):
+    """pg_build_potrf_trtri_checked: the time-out is repaired INSIDE the call (rebuild + classic chain); the caller sees info = 0,
+    LAPACK's factor (1e-11) and inverse, pg_coupled_chain() == 0 afterwards, and the next call is as fast as the classic chain."""
+    import time
+
+    from pygpr_amd._ops import pad_to
+
+    n, d = 3000, 5
+    covs = [orc.SE, orc.WN]
+    x, _ = orc.synth(n, d, seed=31)
+    hp = np.array([1.0, 0.9, 1.1, 0.8, 1.2, 1.0, 0.1])
+    npad = pad_to(n)
+    spec, hpd, xd = _spec(covs, d), dev(hp), dev(x)
+    a = ops.empty(npad, npad)
+    invd = ops.potrf_workspace(npad, torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    minv = ops.zeros(npad, npad) if with_inv else None
+    before = ops.chain_timeouts()
+    assert ops.build_factor_checked(spec, hpd, xd, a, invd, info, minv, jitter=1e-7) == 0
+    assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0 and ops.last_coupled_panels() == 0
+    k = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    chol = np.linalg.cholesky(k)
+    np.testing.assert_allclose(np.tril(host(a))[:n, :n], chol, atol=1e-11)
+    if with_inv:
+        np.testing.assert_allclose(np.tril(host(minv))[:n, :n], np.linalg.inv(chol), atol=1e-8)
+    # next call: no time-out left to wait for (a 2 s budget would show), classic chain
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert ops.build_factor_checked(spec, hpd, xd, a, invd, info, minv, jitter=1e-7) == 0
+    assert time.perf_counter() - t0 < 0.25 and ops.last_coupled_panels() == 0

@@ -35,7 +35,9 @@ def test_library_loads_and_exports_every_header_symbol():
     for n in names:
         assert isinstance(getattr(lib, n), ctypes._CFuncPtr)
     assert lib.pg_version() == 100
-    assert lib.pg_potrf_worksize(0, 512) == 512 * 128 + 2 * 512 * 512      # inv_diag + panel inverse + solved panel rows
+    # inv_diag + the coupled chain's flag words (the panel-mode buffers only exist with PG_PANEL_MODE=1)
+    assert lib.pg_potrf_worksize(0, 512) == 512 * 128 + 64 * 4 + 2048
+    assert lib.pg_potrf_worksize(0, 16384) == 16384 * 128 + 64 * 128 + 2048
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -602,3 +602,48 @@ def test_rccl_code_path_single_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script), root, str(29500 + os.getpid() % 2000)], capture_output=True, text=True,
                        timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0 and "NCCL-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_class_surface_survives_a_coupled_chain_timeout():
+    """Exact_GP.update / predict, MLE.loss_and_grad and the full-covariance committee with every wait of the coupled chain forced
+    to expire: each repeats its evaluation on the classic chain and returns the oracle's numbers -- no exception, as
+    tc.cholesky (PyGPR/gpr.py:69) never fails on a positive-definite matrix."""
+    from pygpr_amd._ops import get_ops
+
+    ops = get_ops()
+    n, d, m = 1700, 4, 40          # pads to 1792: four outer panels, all on the coupled chain
+    x, y = orc.synth(n, d, seed=3)
+    xp = np.random.default_rng(8).random((m, d))
+    hp = np.concatenate([[1.1], np.full(d, 0.9), [0.1]])
+    covs = [orc.SE, orc.WN]
+    l_ref, g_ref = orc.mle_loss_and_grad(covs, hp, x, y, "kinv")
+    mu_ref, var_ref = orc.gp_predict(covs, hp, x, y, xp, "diag")
+    assert ops.coupled_chain() == 1
+    try:
+        for eager in (False, True):
+            ops.set_coupled_chain(1)
+            ops.set_spin_budget(-1)
+            before = ops.chain_timeouts()
+            gp = pg.Exact_GP(T(x), T(y), pg.Compose([pg.Squared_exponential(), pg.White_noise()]), eager_inverse=eager)
+            gp.set_params(T(hp))
+            mu, var = gp.predict(T(xp), var="diag")
+            assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0
+            np.testing.assert_allclose(N(mu), mu_ref, atol=1e-9)
+            np.testing.assert_allclose(N(var), var_ref, atol=1e-10)
+        ops.set_coupled_chain(1)
+        ops.set_spin_budget(-1)
+        before = ops.chain_timeouts()
+        loss = pg.MLE(gp)
+        loss.memoize = False
+        val, grad = loss.loss_and_grad(hp.copy())
+        assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0
+        np.testing.assert_allclose(val, l_ref, rtol=1e-10)
+        np.testing.assert_allclose(grad, g_ref, rtol=1e-8, atol=1e-8 * np.abs(g_ref).max())
+    finally:
+        ops.set_spin_budget(2_000_000)
+        ops.set_coupled_chain(1)
+    assert ops.coupled_chain() == 1
+    val2, _ = pg.MLE(gp).loss_and_grad(hp.copy())          # re-armed: the coupled chain runs again and agrees
+    assert ops.last_coupled_panels() > 0
+    np.testing.assert_allclose(val2, l_ref, rtol=1e-10)
