@@ -131,6 +131,50 @@ def cpu_baseline_as_written(n_full, d, n_cpu):
     }
 
 
+def check_committee(g, xs, hp, n_train_check=1024):
+    """Asserted check of a grBCM committee at whatever size it was built (bench leg and tests/test_parity_gpu.py):
+      (i)  the device aggregation (pg_grbcm_local_terms -> all-reduce -> pg_grbcm_finish, PyGPR/gr_bcm.py:116-149) of one batch
+           against the oracle's restatement of GRBCM.aggregate fed with the SAME per-expert device means / variances;
+      (ii) every owned expert's factor solves its system: predicting an expert's own training inputs gives
+           K alpha' = y - (sigma_n^2 + jitter) alpha (PyGPR/gpr.py:65-85), no O(n^3) oracle run needed.
+    Returns the measured errors; raises AssertionError beyond the stated tolerances (mean 1e-9, variance rtol 1e-9, K alpha 1e-7)."""
+    from oracle import pygpr_oracle as orc
+    from pygpr_amd._ops import get_ops
+
+    ops = get_ops()
+    hp = np.asarray(hp, dtype=np.float64)
+    xsd = ops.to_device(xs.reshape(-1, xs.shape[-1]), g.gpg.dtype)
+    mg, vg = g.gpg._predict_device(xsd, "diag")
+    ml, vl = g.gpl._predict_device(xsd, "diag") if g.gpl is not None else ([], [])
+    mu, var = g.predict(xs, var="diag")
+    out = {"batch": int(xsd.shape[0]), "experts_checked": len(ml)}
+    if not g.distributed:
+        cpu = lambda t: t.detach().cpu().double().numpy()  # noqa: E731
+        mu_o, var_o, beta_o, prec_o = orc.grbcm_aggregate(cpu(mg[0]), cpu(vg[0]), np.stack([cpu(t) for t in ml]),
+                                                          np.stack([cpu(t) for t in vl]))
+        out["aggregate_mean_abs_err"] = float(np.abs(cpu(mu) - mu_o).max())
+        out["aggregate_var_rel_err"] = float(np.abs(cpu(var) / var_o - 1.0).max())
+        out["beta_abs_err"] = float(np.abs(cpu(g.beta) - beta_o).max())
+        assert out["aggregate_mean_abs_err"] < 1e-9 and out["aggregate_var_rel_err"] < 1e-9 and out["beta_abs_err"] < 1e-9, out
+        assert np.all(var_o > 0) and np.all(np.isfinite(mu_o))
+    # K alpha = y per expert (the global expert too)
+    noise = float(hp[-1] ** 2 + 1e-7)
+    worst = 0.0
+    for gp in ([g.gpg] + ([g.gpl] if g.gpl is not None else [])):
+        x3 = gp._x.reshape(-1, gp._x.shape[-2], gp._x.shape[-1])
+        y2 = gp._y.reshape(-1, gp._y.shape[-1])
+        k = min(n_train_check, x3.shape[1])
+        xq = ops.to_device(x3[:, -k:, :].contiguous(), gp.dtype)        # the LAST k points: an expert's own shard, not the shared global set
+        means, _ = gp._predict_device(xq if x3.shape[0] > 1 else xq[0], "none")
+        alpha = gp.wt.reshape(y2.shape[0], -1)
+        for c, m_c in enumerate(means):
+            resid = m_c.detach().cpu().double().numpy() - (y2[c, -k:].double().numpy() - noise * alpha[c, -k:].double().cpu().numpy())
+            worst = max(worst, float(np.abs(resid).max()))
+    out["k_alpha_eq_y_abs_err"] = worst
+    assert worst < 1e-7, out
+    return out
+
+
 def launch_ranks(n):
     """`--gpus N` from a bare shell: start N fresh rank processes and relay their output.  Nothing in this process has
     touched the GPU yet (importing torch and counting devices do not), and it never execs: the launcher is a child."""
@@ -201,10 +245,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def dist_report(nwords):
-        """Who took part: every rank reports (rank, device index); the shared-gradient all-reduce is timed alone."""
+    def dist_report(nwords, mine=None):
+        """Who took part: every rank reports (rank, device index) and -- after the timed loop -- its own record `mine`
+        (ms_per_step, device name, coupled-chain state, panels of its last factorisation that ran coupled, time-outs seen);
+        the shared-gradient all-reduce is timed alone.  A rank that fell back to the classic chain or sits on a slower
+        box shows up here instead of vanishing in the max-over-ranks time."""
         if world == 1:
-            return {"backend": None, "world": 1, "ranks": [0], "devices": [dev_index]}
+            rep = {"backend": None, "world": 1, "ranks": [0], "devices": [dev_index]}
+            if mine is not None:
+                rep["per_rank"] = [mine]
+            return rep
         me = torch.tensor([rank, dev_index], dtype=torch.int64, device=cdev)
         got = [torch.zeros_like(me) for _ in range(world)]
         dist.all_gather(got, me)
@@ -218,13 +268,18 @@ def main():
             dist.all_reduce(buf)
         sync()
         t_ar = max_over_ranks((time.perf_counter() - t0) / 50)
-        return {"backend": dist.get_backend(), "world": dist.get_world_size(),
-                "ranks": [int(g[0]) for g in got], "devices": [int(g[1]) for g in got],
-                "allreduce_us": 1e6 * t_ar, "allreduce_doubles": int(buf.numel()),
-                "transport": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal: ranks may share GPUs)"}
+        rep = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+               "ranks": [int(g[0]) for g in got], "devices": [int(g[1]) for g in got],
+               "allreduce_us": 1e6 * t_ar, "allreduce_doubles": int(buf.numel()),
+               "transport": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal: ranks may share GPUs)"}
+        if mine is not None:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            rep["per_rank"] = every
+        return rep
 
     if args.rendezvous_only:
-        rep = dist_report(2 + args.d + 2)
+        rep = dist_report(1 + (args.d + 2) + world)
         if rank == 0:
             print(json.dumps({"dist": rep}), flush=True)
         if world > 1:
@@ -263,10 +318,23 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         val, grad = loss.loss_and_grad(hp)
-    barrier()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0          # this rank's own clock up to its last step (the steps themselves are in
+    barrier()                                         # lockstep through the all-reduce; see ms_per_eval_alone below)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed)
     value = world * args.steps / elapsed
+    # every rank alone, no collective: what tells a slow box or a rank on the classic chain from the others
+    alone = pg.MLE(model.gpl)
+    alone.memoize = False
+    alone.loss_and_grad(hp[None, :].copy())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        alone.loss_and_grad(hp[None, :].copy())
+    torch.cuda.synchronize()
+    ms_alone = 1e3 * (time.perf_counter() - t1) / 3
+    del alone
 
     out = {
         "metric": "NLML+grad evals/sec at N=%d D=%d RBF" % (n, d), "value": value, "unit": "evals/s",
@@ -282,7 +350,11 @@ def main():
         "build": _lib.build_id(),
     }
 
-    out["dist"] = dist_report(2 + d + 2)      # [NLML, gradient (nhp = d + 2), status]
+    mine = {"rank": rank, "device_index": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+            "ms_per_step": 1e3 * elapsed_local / args.steps, "ms_per_eval_alone": ms_alone, "coupled_chain": ops.coupled_chain(),
+            "coupled_panels_last_potrf": ops.last_coupled_panels(), "chain_timeouts": ops.chain_timeouts(),
+            "fallbacks": int(getattr(ops, "fallbacks", 0))}
+    out["dist"] = dist_report(1 + (d + 2) + world, mine)      # [NLML, gradient (nhp = d + 2), one status word per rank]
 
     local = exp = None
     if rank == 0:
@@ -296,7 +368,11 @@ def main():
         torch.cuda.synchronize()
         ops.profile(0)
         flops, ms, launches = ops.profile_read()
-        achieved = flops / ms / 1e9 if ms > 0 else 0.0
+        # ALGORITHMIC flop of one evaluation (n^3/3 potrf + n^3/3 L^-1 + n^3/3 L^-T L^-1 = n^3) over the summed
+        # durations of the GEMM-core launches that carry them.  The launches execute whole 128-wide diagonal tiles (2.5 % more
+        # flop than n^3 at n = 16384): that tile-granular count is reported beside it, never as `achieved`.
+        algo = float(n) ** 3
+        achieved = algo / ms / 1e9 if ms > 0 else 0.0
         eval_tflops = float(n) ** 3 / (elapsed / args.steps) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -304,15 +380,18 @@ def main():
             "kernel": "pg_gemm_kernel<double,...> (MFMA GEMM core, all instantiations) over one evaluation",
             "profile_mode": "single-stream: look-ahead off, every GEMM-core launch timed alone with HIP events on its launch "
                             "stream (pg_profile); frac is the GEMM core's, frac_end_to_end the headline schedule's",
-            "launches": launches, "avg_launch_ms": ms / max(launches, 1), "flops_per_launch": flops / max(launches, 1),
-            "algorithmic_flops_per_eval": float(n) ** 3, "eval_tflops": eval_tflops,
+            "launches": launches, "avg_launch_ms": ms / max(launches, 1), "flops_per_launch": algo / max(launches, 1),
+            "algorithmic_flops_per_eval": algo, "eval_tflops": eval_tflops,
             "frac_end_to_end": eval_tflops / FP64_MATRIX_PEAK_TFLOPS,
+            "tile_granular": {"flops_per_eval": flops, "achieved": flops / ms / 1e9 if ms > 0 else 0.0,
+                              "frac": (flops / ms / 1e9 if ms > 0 else 0.0) / FP64_MATRIX_PEAK_TFLOPS,
+                              "note": "flop the launches execute, counting whole 128 x 128 tiles on the diagonal (pg_gemm_flops)"},
         }
         # HBM-side bytes of the GEMM-core launches: PMC counters cannot be read from inside this process; they come
         # from separate rocprofv3 --pmc passes over the same evaluation (tools/probe_eval_once.py, tools/pmc_summary.py),
         # committed under profiles/ together with the identity of the build they were taken on.  A summary taken on
         # another build (kernel sources changed since) is not reported.
-        pmc_name = "r02_pmc_eval_traffic.json"
+        pmc_name = "r03_pmc_eval_traffic.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if n == 16384 and os.path.exists(pmc):
             with open(pmc) as fh:
@@ -455,14 +534,28 @@ def main():
         t0 = time.perf_counter()
         for s in range(0, m4, mb):
             mu, var = g4.predict(xs[s: s + mb])
+        torch.cuda.synchronize()
+        tp_local = time.perf_counter() - t0
         barrier()
         tp = time.perf_counter() - t0
         tp = max_over_ranks(tp)
+        flop4 = float(m4) * (nc * float(ng4 + nls4) ** 2 + float(ng4) ** 2)     # n^2 flop per test point per expert
+        per_rank = [tp]
+        if world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, float(tp_local))
+            per_rank = got
         out["grbcm_predict"] = {
-            "value": m4 / tp, "unit": "points/s", "scaling": "strong", "seconds": tp,
+            "value": m4 / tp, "unit": "points/s", "scaling": "strong", "seconds": tp, "seconds_per_rank": per_rank,
             "config": "8 experts x (%d global + %d local) points, D=%d, RBF+noise fp64, %d test points in batches of %d, "
                       "diag variance; experts sharded over %d rank(s); one [3,m] all-reduce per batch" % (ng4, nls4, d4, m4, mb, world),
             "mean_abs": float(mu.abs().mean()), "var_mean": float(var.mean()),
+            "roofline": {"bound": "mfma", "achieved": flop4 / tp / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": flop4 / tp / 1e12 / (FP64_MATRIX_PEAK_TFLOPS * world), "algorithmic_flops": flop4,
+                         "kernel": "pg_gemm_kernel<double,...> column-sum epilogue (variance product L^-1 K*^T), all experts",
+                         "note": "flop = m (nc n^2 + ng^2): the triangular variance product per test point per expert (SURVEY 8d); "
+                                 "K* build, mean and aggregation are lower order"},
+            "check": check_committee(g4, xs[:mb].cpu(), hp4.numpy()),
         }
         del g4, xs
 

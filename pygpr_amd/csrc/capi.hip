@@ -68,10 +68,16 @@ void pg_set_error(const char* fmt, ...) {
 // factorises on the classic chain (no flags, no resident kernels), so that repeating the failed call -- which is what
 // pg_build_potrf_trtri_checked and the Python layer do -- ends in a correct factor.  pg_set_coupled_chain(h, 1) probes and re-arms.
 static void poll_timeout(pg_ctx* h) {
-    if (h && h->tmo_host && *(volatile int*)h->tmo_host) {
-        *(volatile int*)h->tmo_host = 0;
-        h->coupled = 0;
-        h->timeouts += 1;
+    if (h && h->tmo_host) {
+        const int v = *(volatile int*)h->tmo_host;     // epoch of the factorisation whose wait expired (chainstep.h)
+        if (v) {
+            *(volatile int*)h->tmo_host = 0;
+            h->coupled = 0;
+            if (v != h->counted_epoch) {               // one count per call, however many waits expired and whenever we looked
+                h->counted_epoch = v;
+                h->timeouts += 1;
+            }
+        }
     }
 }
 

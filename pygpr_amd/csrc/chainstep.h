@@ -13,11 +13,13 @@ struct CsWait {
     int* tmo;
     int* tmo_host;
     long long ticks;
+    int epoch;        // which factorisation of the handle this is (> 0): what an expiry writes to *tmo_host, so that the host counts
+                      // one time-out per call however many of its waits expire and whenever it polls
 };
 #define PG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ void cs_expire(const CsWait& w) {
     __hip_atomic_store(w.tmo, 1, PG_RLX_AGENT);
-    if (w.tmo_host) __hip_atomic_store(w.tmo_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (w.tmo_host) __hip_atomic_store(w.tmo_host, w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ bool cs_spin_ge(int* flag, int want, const CsWait& w) {   // ONE lane
     if (w.ticks < 0) {

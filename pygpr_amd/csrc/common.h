@@ -35,6 +35,8 @@ struct pg_ctx {
     int* tmo_dev;             // its device address
     long long spin_ticks;     // budget of one wait of the coupled chain in 10 ns ticks (< 0: forced expiry, test hook)
     int timeouts;             // coupled-chain time-outs seen on this handle (each switched the handle to the classic chain)
+    int chain_epoch;          // counts the factorisations that took the coupled chain; an expiry reports its call's number
+    int counted_epoch;        // the last epoch whose time-out was counted
     int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;

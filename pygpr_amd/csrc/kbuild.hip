@@ -15,6 +15,7 @@
 // (covar.py:169-206), dK/dsigma_n = 2 sigma_n I (covar.py:247-269).  The reference materialises
 // dK[nhp,n,n] and solves against it (loss.py:116-121); this is the same number by the K^-1 route.
 #include "kbuild.h"
+#include <cstdlib>
 
 #define KT 64
 #define TLD 65     // odd leading dimension of the LDS transpose tile: column writes are at worst 2-way conflicted
@@ -58,50 +59,60 @@ template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, 
 }
 
 template <typename T>
-__device__ __forceinline__ void stage_points(T* dst, const T* __restrict__ X, long ldx, int npts, int p0, int d, int tid) {
-    // dst[k][64] <- X[p0 + p][k]; points beyond npts read as zero
+__device__ __forceinline__ void stage_points(T* dst, const T* __restrict__ X, long ldx, int npts, int p0, int d, int tid,
+                                             const double* __restrict__ scale = nullptr) {
+    // dst[k][64] <- X[p0 + p][k] (* scale[k]: coordinates pre-multiplied by the inverse length scales); points beyond npts read as zero
     for (int idx = tid; idx < KT * d; idx += 256) {
         const int p = idx / d, k = idx % d;
         const int gp = p0 + p;
-        dst[k * KT + p] = (gp < npts) ? X[(long)gp * ldx + k] : (T)0;
+        T v = (gp < npts) ? X[(long)gp * ldx + k] : (T)0;
+        if (scale) v = (T)((double)v * scale[k]);
+        dst[k * KT + p] = v;
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
-                                                        const T* __restrict__ Xr, long ldr, int nr,
-                                                        const T* __restrict__ Xc, long ldc, int nc, int d,
-                                                        int symmetric, int lower_only, int accumulate, double jitter,
-                                                        T* __restrict__ K, long ldk, int ctile0) {
-    const int tc = blockIdx.x + ctile0, tr = blockIdx.y;   // ctile0: first column tile of the window this launch builds
-    // symmetric builds evaluate only tiles on/below the diagonal; lower_only == 0 also writes the mirror image
-    if (symmetric && tc > tr) return;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* xr = reinterpret_cast<T*>(smem_raw);
-    T* xc = xr + KT * d;
-    T* l2 = xc + KT * d;   // [ncomp][d] squared inverse length scales
-    T* tt = l2 + PG_MAX_COMP * d;   // [64][TLD] transposed tile for the mirrored store (symmetric, off-diagonal)
-    const int tid = threadIdx.x;
-    stage_points(xr, Xr, ldr, nr, tr * KT, d, tid);
-    stage_points(xc, Xc, ldc, nc, tc * KT, d, tid);
-    for (int idx = tid; idx < spec.ncomp * d; idx += 256) {
-        const int c = idx / d, k = idx % d;
-        const double l = hp[spec.off[c] + 1 + k];
-        l2[idx] = (T)(l * l);
+// Tile (tr, tc) of workgroup `b` of a 1-D grid.  Symmetric builds launch ONLY the tiles on or below the diagonal (round 2
+// launched the full square and let the upper half exit at once): column window [c0, c1) in tiles, T tile rows --
+//   rows c0 .. c1-1 hold tr - c0 + 1 tiles (the triangle), rows c1 .. T-1 hold c1 - c0 (the rectangle below it).
+__device__ __forceinline__ void kb_tile_of(int b, int symmetric, int c0, int c1, int& tr, int& tc) {
+    const int W = c1 - c0;
+    if (!symmetric) {
+        tr = b / W;
+        tc = c0 + b % W;
+        return;
     }
-    __syncthreads();
+    const int ntri = W * (W + 1) / 2;
+    if (b < ntri) {
+        int r = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > b) --r;
+        while ((r + 1) * (r + 2) / 2 <= b) ++r;
+        tr = c0 + r;
+        tc = c0 + b - r * (r + 1) / 2;
+    } else {
+        const int j = b - ntri;
+        tr = c1 + j / W;
+        tc = c0 + j % W;
+    }
+}
 
+// The 4 x 4 micro-tile of one thread: rows ty*4 + r, columns two (fp64) or one (fp32) 16-byte vectors at v*(16*VE) + tx*VE.
+//   PRESC  : one stationary component whose inverse length scales were folded into the staged coordinates (sq += df * df)
+//   CHECKED: the tile touches the diagonal, the padding or an accumulate pass -- per-element fix-ups; interior tiles skip them
+// The kernel is bound by fp64 VALU issue, not by HBM, at d = 8 (about 250 VALU cycles per 64 elements against the 120 their
+// stores take at 5.3 TB/s): both switches only remove instructions.
+template <typename T, bool PRESC, bool CHECKED, bool MIRROR>
+__device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, const T* xc, const T* l2, const T* sg2, T* tt, int d,
+                                        int tr, int tc, int nr, int nc, int symmetric, int accumulate, T* __restrict__ K, long ldk,
+                                        int tid) {
     constexpr int VE = VecOf<T>::N, NVC = 4 / VE;   // vectors per row of the micro-tile
+    typedef typename VecOf<T>::type vec_t;
     const int tx = tid & 15, ty = tid >> 4;
     T out[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[r][c] = (T)0;
-
     for (int cp = 0; cp < spec.ncomp; ++cp) {
-        const double sg = hp[spec.off[cp]];
-        const T sig2 = (T)(sg * sg);
         const T* lc = l2 + cp * d;
         T sq[4][4];
 #pragma unroll
@@ -109,67 +120,126 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
 #pragma unroll
             for (int c = 0; c < 4; ++c) sq[r][c] = (T)0;
         for (int k = 0; k < d; ++k) {
-            const T w = lc[k];
             T a[4], b[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = xr[k * KT + ty * 4 + r];
 #pragma unroll
-            for (int v = 0; v < NVC; ++v)
+            for (int v = 0; v < NVC; ++v) {
+                const vec_t bv = *reinterpret_cast<const vec_t*>(xc + k * KT + v * (16 * VE) + tx * VE);
 #pragma unroll
-                for (int e = 0; e < VE; ++e) b[v * VE + e] = xc[k * KT + v * (16 * VE) + tx * VE + e];
+                for (int e = 0; e < VE; ++e) b[v * VE + e] = bv[e];
+            }
+            if (PRESC) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const T df = a[r] - b[c];
-                    sq[r][c] += w * df * df;
-                }
+                    for (int c = 0; c < 4; ++c) {
+                        const T df = a[r] - b[c];
+                        sq[r][c] += df * df;
+                    }
+            } else {
+                const T w = lc[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const T df = a[r] - b[c];
+                        sq[r][c] += w * df * df;
+                    }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[r][c] += comp_value<T>(spec.kind[cp], sig2, sq[r][c]);
+            for (int c = 0; c < 4; ++c) out[r][c] += comp_value<T>(spec.kind[cp], sg2[cp], sq[r][c]);
     }
-    double dg = jitter;
-    for (int i = 0; i < spec.nnoise; ++i) { const double s = hp[spec.noise_off[i]]; dg += s * s; }
-
-    const bool mirror = symmetric && !lower_only && tc < tr;
+    const T dg = sg2[PG_MAX_COMP];
+    const bool mirror = MIRROR && tc < tr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int gi = tr * KT + ty * 4 + r;
 #pragma unroll
         for (int v = 0; v < NVC; ++v) {
-            typename VecOf<T>::type vec;
+            vec_t vec;
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                const int gj = tc * KT + v * (16 * VE) + tx * VE + e;
                 T val = out[r][v * VE + e];
-                if (gi >= nr || gj >= nc) val = (symmetric && gi == gj && !accumulate) ? (T)1 : (T)0;
-                else if (symmetric && gi == gj) val += (T)dg;
+                if (CHECKED) {
+                    const int gj = tc * KT + v * (16 * VE) + tx * VE + e;
+                    if (gi >= nr || gj >= nc) val = (symmetric && gi == gj && !accumulate) ? (T)1 : (T)0;
+                    else if (symmetric && gi == gj) val += dg;
+                }
                 vec[e] = val;
-                if (mirror) tt[(v * (16 * VE) + tx * VE + e) * TLD + ty * 4 + r] = val;
+                if (MIRROR) { if (mirror) tt[(v * (16 * VE) + tx * VE + e) * TLD + ty * 4 + r] = val; }
             }
-            typename VecOf<T>::type* dst = reinterpret_cast<typename VecOf<T>::type*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE);
-            if (accumulate) vec += *dst;    // a further pass of a Compose with more than PG_MAX_COMP children
+            vec_t* dst = reinterpret_cast<vec_t*>(K + (long)gi * ldk + tc * KT + v * (16 * VE) + tx * VE);
+            if (CHECKED) { if (accumulate) vec += *dst; }   // a further pass of a Compose with more than PG_MAX_COMP children
             *dst = vec;
         }
     }
-    if (mirror) {   // K[tc-tile rows][tr-tile cols] = transpose, read back row-wise so the stores stay 256-byte runs
+    if (MIRROR && mirror) {   // K[tc-tile rows][tr-tile cols] = transpose, read back row-wise so the stores stay 256-byte runs
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int li = ty * 4 + r;
 #pragma unroll
             for (int v = 0; v < NVC; ++v) {
-                typename VecOf<T>::type vec;
+                vec_t vec;
 #pragma unroll
                 for (int e = 0; e < VE; ++e) vec[e] = tt[li * TLD + v * (16 * VE) + tx * VE + e];
-                typename VecOf<T>::type* dst = reinterpret_cast<typename VecOf<T>::type*>(K + (long)(tc * KT + li) * ldk + tr * KT + v * (16 * VE) + tx * VE);
-                if (accumulate) vec += *dst;
+                vec_t* dst = reinterpret_cast<vec_t*>(K + (long)(tc * KT + li) * ldk + tr * KT + v * (16 * VE) + tx * VE);
+                if (CHECKED) { if (accumulate) vec += *dst; }
                 *dst = vec;
             }
         }
     }
+}
+
+template <typename T, bool MIRROR>   // MIRROR: a symmetric build that also writes the transposed tiles above the diagonal
+__global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
+                                                        const T* __restrict__ Xr, long ldr, int nr,
+                                                        const T* __restrict__ Xc, long ldc, int nc, int d,
+                                                        int symmetric, int accumulate, double jitter,
+                                                        T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int sq_grid) {
+    int tr, tc;
+    kb_tile_of(blockIdx.x, symmetric && !sq_grid, ctile0, ctile1, tr, tc);
+    if (sq_grid && symmetric && tc > tr) return;    // PG_KB_GRID2D=1 (experiment): round 2's full-square grid
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* xr = reinterpret_cast<T*>(smem_raw);
+    T* xc = xr + KT * d;
+    T* l2 = xc + KT * d;            // [ncomp][d] squared inverse length scales
+    T* sg2 = l2 + PG_MAX_COMP * d;  // [PG_MAX_COMP] sigma^2, then the diagonal term
+    T* tt = sg2 + PG_MAX_COMP + 2;  // MIRROR: [64][TLD] transposed tile
+    const int tid = threadIdx.x;
+    const double* scale = presc ? hp + spec.off[0] + 1 : nullptr;
+    stage_points(xr, Xr, ldr, nr, tr * KT, d, tid, scale);
+    stage_points(xc, Xc, ldc, nc, tc * KT, d, tid, scale);
+    for (int idx = tid; idx < spec.ncomp * d; idx += 256) {
+        const int c = idx / d, k = idx % d;
+        const double l = hp[spec.off[c] + 1 + k];
+        l2[idx] = (T)(l * l);
+    }
+    if (tid < spec.ncomp) {
+        const double sg = hp[spec.off[tid]];
+        sg2[tid] = (T)(sg * sg);
+    }
+    if (tid == 64) {
+        double dg = jitter;
+        for (int i = 0; i < spec.nnoise; ++i) { const double s = hp[spec.noise_off[i]]; dg += s * s; }
+        sg2[PG_MAX_COMP] = (T)dg;
+    }
+    __syncthreads();
+    // workgroup-uniform: a tile strictly below the diagonal (or any tile of a cross build) that lies inside the real points
+    const bool interior = !accumulate && (!symmetric || tc < tr) && (tr + 1) * KT <= nr && (tc + 1) * KT <= nc;
+#define KB_ARGS spec, xr, xc, l2, sg2, tt, d, tr, tc, nr, nc, symmetric, accumulate, K, ldk, tid
+    if (presc) {
+        if (interior) kb_body<T, true, false, MIRROR>(KB_ARGS);
+        else kb_body<T, true, true, MIRROR>(KB_ARGS);
+    } else {
+        if (interior) kb_body<T, false, false, MIRROR>(KB_ARGS);
+        else kb_body<T, false, true, MIRROR>(KB_ARGS);
+    }
+#undef KB_ARGS
 }
 
 template <typename T>
@@ -180,11 +250,14 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
     }
-    const size_t lds = (size_t)(2 * KT * d + PG_MAX_COMP * d + (symmetric && !lower_only ? KT * TLD : 0)) * sizeof(T);
+    const bool mirror = symmetric && !lower_only;
+    const size_t lds = (size_t)(2 * KT * d + PG_MAX_COMP * d + PG_MAX_COMP + 2 + (mirror ? KT * TLD : 0)) * sizeof(T);
     static bool attr_done = false;
     if (!attr_done) {   // the mirrored fp64 build passes the 64 KB a kernel gets without opting in from d = 31 (101 KB at d = 64)
-        const size_t lds_max = (size_t)(2 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + KT * TLD) * sizeof(T);
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T>),
+        const size_t lds_max = (size_t)(2 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD) * sizeof(T);
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
@@ -195,13 +268,25 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         pg_set_error("pg_kbuild: bad column window [%d, %d)", col0, col1);
         return -2;
     }
-    if (symmetric && !lower_only && (col0 != 0 || col1 != cols_pad)) {
+    if (mirror && (col0 != 0 || col1 != cols_pad)) {
         pg_set_error("pg_kbuild: a mirrored build cannot be windowed");
         return -2;
     }
-    dim3 grid((col1 - col0) / KT, rows_pad / KT);
-    hipLaunchKernelGGL(pg_kbuild_kernel<T>, grid, dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                       symmetric, lower_only, accumulate, jitter, K, ldk, col0 / KT);
+    const int c0 = col0 / KT, c1 = col1 / KT, W = c1 - c0, TR = rows_pad / KT;
+    // symmetric: the triangle of the window's own tile rows plus the rectangle below it; cross build: every tile of the window
+    static const int sq_grid = getenv("PG_KB_GRID2D") ? atoi(getenv("PG_KB_GRID2D")) : 0;
+    const long tiles = (symmetric && !sq_grid) ? (long)W * (W + 1) / 2 + (long)(TR - c1) * W : (long)TR * W;
+    if (tiles <= 0) return 0;
+    // one stationary component (the common Compose([SE, WN])): its inverse length scales go into the staged coordinates.  In fp64
+    // (x l) - (x' l) rounds differently from l^2 (x - x')^2 in the last bit; PG_KB_PRESC=0 keeps the unscaled form
+    static const int presc_env = getenv("PG_KB_PRESC") ? atoi(getenv("PG_KB_PRESC")) : 1;
+    const int presc = (presc_env && spec.ncomp == 1) ? 1 : 0;
+    if (mirror)
+        hipLaunchKernelGGL((pg_kbuild_kernel<T, true>), dim3((unsigned)tiles), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
+                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid);
+    else
+        hipLaunchKernelGGL((pg_kbuild_kernel<T, false>), dim3((unsigned)tiles), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
+                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid);
     PG_CHECK(hipGetLastError());
     return 0;
 }

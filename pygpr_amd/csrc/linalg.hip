@@ -555,7 +555,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     int* f_done = f_diag + nblk;                // [nblk] leaf b has stored L_bb and its inverse
     int* f_brow = f_done + nblk;                // [nblk] workgroups that have published X[block row b+1, block column b]
     int* f_tmo = f_brow + nblk;                 // sticky time-out word
-    const CsWait cw = {f_tmo, ctx->tmo_dev, ctx->spin_ticks};
+    if (o_s < npan) ctx->chain_epoch = ctx->chain_epoch % 1000000 + 1;
+    const CsWait cw = {f_tmo, ctx->tmo_dev, ctx->spin_ticks, ctx->chain_epoch};
     if (o_s < npan) {
         PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((3 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
     }

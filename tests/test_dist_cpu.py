@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cases=(0, 1, 2)):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -27,11 +27,16 @@ def _worker(rank, world, port, out_dir):
     g = np.load(os.path.join(HERE, "golden", "grbcm.npz"))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
     res = {}
-    for case in (0, 1, 2):          # nc = 2, 4, 8 experts over 2 ranks
+    from pygpr_amd.gr_bcm import expert_block
+
+    for case in cases:              # nc = 2, 4, 8 experts over the ranks (uneven blocks, and ranks without an expert, for world = 3)
         p = "g%d_" % case
         cov = pg.Compose([pg.Squared_exponential(), pg.White_noise()])
         m = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), cov, distributed=True)
-        assert m.world == world and m.hi - m.lo == g[p + "xl"].shape[0] // world
+        nc = g[p + "xl"].shape[0]
+        assert m.world == world and (m.lo, m.hi) == expert_block(nc, rank, world)
+        assert (m.gpl is None) == (m.hi == m.lo)
+        res["nloc%d" % case] = np.array(m.hi - m.lo)
         m.gpg.set_params(T(g[p + "hpg"]))
         m.set_local_params(T(g[p + "hpl"]))
         mu, var = m.predict(T(g[p + "xs"]), var="diag")
@@ -43,10 +48,11 @@ def _worker(rank, world, port, out_dir):
         m.set_params(T(g[p + "hpg"]))
         mu_f, cov_f = m.predict(T(g[p + "xs"]), var="full")
         res["muf%d" % case], res["covf%d" % case] = mu_f.numpy(), cov_f.numpy()
-    # a non-positive-definite expert on the LAST rank only: every rank must raise, none may hang in the collective
+    # a non-positive-definite expert (the last one) on ONE rank only: every rank must raise, none may hang in the collective
     p = "g1_"
     xl = g[p + "xl"].copy()
     xl[-1, 3, 0] = np.nan
+    owner = [r for r in range(world) if expert_block(xl.shape[0], r, world)[0] <= xl.shape[0] - 1 < expert_block(xl.shape[0], r, world)[1]][0]
     bad = pg.GRBCM(T(xl), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), pg.Compose([pg.Squared_exponential(), pg.White_noise()]),
                    distributed=True)
     bad.set_params(T(g[p + "hpg"]))
@@ -57,22 +63,24 @@ def _worker(rank, world, port, out_dir):
             call()
             raised.append(0)
         except torch.linalg.LinAlgError as err:
-            raised.append(2 if "reported by rank %d" % (world - 1) in str(err) else 1)
+            raised.append(2 if "reported by rank %d" % owner in str(err) else 1)
     res["raised"] = np.array(raised)
+    res["owner"] = np.array(owner)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grbcm_two_ranks_gloo(tmp_path, golden):
+def _run_and_check(tmp_path, golden, world, cases):
     from oracle import pygpr_oracle as orc
 
-    world, port = 2, 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() + 7 * world) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), cases), nprocs=world, join=True)
     g = golden("grbcm")
     outs = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
-    for case in (0, 1, 2):
+    for case in cases:
         p = "g%d_" % case
+        assert sum(int(o["nloc%d" % case]) for o in outs) == g[p + "xl"].shape[0]
         for o in outs:                                  # every rank finishes with the full committee answer
             np.testing.assert_allclose(o["mu%d" % case], g[p + "mu"], atol=1e-10)
             np.testing.assert_allclose(o["var%d" % case], g[p + "var"], atol=1e-11)
@@ -83,9 +91,24 @@ def test_grbcm_two_ranks_gloo(tmp_path, golden):
             np.testing.assert_allclose(o["grad%d" % case], sum(r[1] for r in ref), rtol=1e-8, atol=1e-8)
             np.testing.assert_allclose(o["covf%d" % case], g[p + "cov_full"], rtol=1e-6, atol=1e-10)
             np.testing.assert_allclose(o["muf%d" % case], g[p + "mu_full"], rtol=1e-6, atol=1e-9)
-    # failure on the last rank: it raises its own error (1), the other rank the relayed one (2) -- in all three calls
-    assert outs[world - 1]["raised"].tolist() == [1, 1, 1]
-    assert outs[0]["raised"].tolist() == [2, 2, 2]
+    # failure on one rank: it raises its own error (1), every other rank the relayed one naming it (2) -- in all three calls
+    owner = int(outs[0]["owner"])
+    for r, o in enumerate(outs):
+        assert o["raised"].tolist() == ([1, 1, 1] if r == owner else [2, 2, 2]), (r, owner, o["raised"])
+    return outs
+
+
+def test_grbcm_two_ranks_gloo(tmp_path, golden):
+    _run_and_check(tmp_path, golden, 2, (0, 1, 2))
+
+
+def test_grbcm_three_ranks_uneven_blocks_and_an_empty_rank(tmp_path, golden):
+    """world = 3: nc = 8 gives blocks of 3, 3, 2 experts; nc = 2 leaves rank 2 WITHOUT a local expert (gpl = None: it still
+    holds the global expert, joins every all-reduce with zero terms and finishes with the committee's answer); the failing
+    expert of the nc = 4 case sits on the middle rank and the last rank owns nothing."""
+    outs = _run_and_check(tmp_path, golden, 3, (0, 2))
+    assert [int(o["nloc0"]) for o in outs] == [1, 1, 0] and [int(o["nloc2"]) for o in outs] == [3, 3, 2]
+    assert int(outs[0]["owner"]) == 1
 
 
 def test_bench_starts_its_own_ranks(tmp_path):

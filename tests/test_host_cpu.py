@@ -149,7 +149,7 @@ def test_grbcm_and_drivers_on_host(fake_ops, golden):
     cg.minimize()
     np.testing.assert_allclose(cg.res.fun, gg["d_res_fun"], rtol=1e-6)
     gam = pg.get_learn_rate(T(gg["a_hp"]), pg.MLE(pg.Exact_GP(T(gg["a_x"]), T(gg["a_y"]), se_wn())), 1e-6)
-    np.testing.assert_allclose(gam, gg["a_gamma"], rtol=5e-2)
+    np.testing.assert_allclose(gam, gg["a_gamma"], rtol=1e-6)     # host logic over the oracle-backed double: the oracle's accuracy
     nm = pg.Nelder_Mead(pg.MLE(gpd))
     nm.args.update(maxiter=3, disp=False)
     before = gpd.params.clone()

@@ -3,7 +3,8 @@
 (PyGPR/tests/test_covar.py, test_gpr.py, test_loss.py, test_grbcm.py) with fixed seeds.
 
 Stated fp64 tolerances: with sigma_n = 0.1 NLML rtol 1e-10, gradient rtol 1e-8 on |g|_inf,
-mean atol 1e-10, variance atol 1e-11; default hp (sigma_n = 1e-4, cond(K) ~ 1e9): NLML 1e-8, grad 1e-5."""
+mean atol 1e-10, variance atol 1e-11; default hp (sigma_n = 1e-4, cond(K) ~ 1e9): NLML 1e-8, gradient 1e-7 (SURVEY: 1e-6;
+measured 1.4e-9 at n = 512, cond(K) = 3.5e9 -- test_default_hp_gradient_error_is_stated prints it)."""
 import os
 
 import numpy as np
@@ -212,7 +213,8 @@ def test_mle_golden(golden):
     assert float(l3) == float(l2) and np.array_equal(g3, g2)
     l0, g0 = mle.loss_and_grad(g["a_hp0"].copy())                      # cond(K) ~ 1e9
     np.testing.assert_allclose(l0, g["a_loss0"], rtol=1e-8)
-    np.testing.assert_allclose(g0, g["a_grad0"], rtol=1e-5, atol=1e-5 * np.abs(g["a_grad0"]).max())
+    # SURVEY 8c states 1e-6 for this class; measured 1.5e-11 (n = 64) and 1.4e-9 (n = 512): test_default_hp_gradient_error_is_stated
+    np.testing.assert_allclose(g0, g["a_grad0"], rtol=1e-7, atol=1e-7 * np.abs(g["a_grad0"]).max())
     # cfg1 known answer
     gpb = pg.Exact_GP(T(g["b_x"]), T(g["b_y"]), se_wn())
     lb, gb = pg.MLE(gpb).loss_and_grad(g["b_hp"].copy())
@@ -220,7 +222,7 @@ def test_mle_golden(golden):
     np.testing.assert_allclose(gb, g["b_grad"], rtol=1e-8, atol=1e-8 * np.abs(g["b_grad"]).max())
     lb0, gb0 = pg.MLE(gpb).loss_and_grad(g["b_hp0"].copy())
     np.testing.assert_allclose(lb0, -3461.42170686, rtol=1e-8)
-    np.testing.assert_allclose(gb0, g["b_grad0"], rtol=1e-5)
+    np.testing.assert_allclose(gb0, g["b_grad0"], rtol=1e-7, atol=1e-7 * np.abs(g["b_grad0"]).max())
     # batched [nc, nhp]
     gpc = pg.Exact_GP(T(g["c_x"]), T(g["c_y"]), se_wn())
     lc, gc = pg.MLE(gpc).loss_and_grad(g["c_hp"].copy())
@@ -252,7 +254,12 @@ def test_learn_rate_and_cg(golden):
     g = golden("gp")
     gp = pg.Exact_GP(T(g["a_x"]), T(g["a_y"]), se_wn())
     gam = pg.get_learn_rate(T(g["a_hp"]), pg.MLE(gp), 1e-6)
-    np.testing.assert_allclose(gam, g["a_gamma"], rtol=5e-2)     # eps = 1e-6 second difference: noisy by nature
+    # eps = 1e-6: a second difference of three NLML values whose rounding (1e-14 relative) is amplified by 1 / eps^2
+    np.testing.assert_allclose(gam, g["a_gamma"], rtol=1e-6)     # measured 8.6e-10
+    r3 = golden("round3")        # the same probe at step sizes above the rounding floor (make_golden_r3.py); measured 1e-14 / 6e-14
+    for tag, rtol in (("3", 1e-10), ("4", 1e-9)):
+        gam = pg.get_learn_rate(T(g["a_hp"]), pg.MLE(gp), float(r3["lr_eps" + tag]))
+        np.testing.assert_allclose(gam, r3["lr_gamma" + tag], rtol=rtol)
     gpd = pg.Exact_GP(T(g["d_x"]), T(g["d_y"]), se_wn())
     gpd.set_params(T(g["d_hp"]))
     cg = pg.CG(pg.MLE(gpd))
@@ -647,3 +654,55 @@ def test_class_surface_survives_a_coupled_chain_timeout():
     val2, _ = pg.MLE(gp).loss_and_grad(hp.copy())          # re-armed: the coupled chain runs again and agrees
     assert ops.last_coupled_panels() > 0
     np.testing.assert_allclose(val2, l_ref, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_cfg4_size_committee():
+    """BASELINE config 4 at its real size: 8 experts x (1024 global + 8192 own) points, D = 16, one batch of 8192 test points.
+    (i) the device aggregation (pg_grbcm_local_terms / pg_grbcm_finish, PyGPR/gr_bcm.py:116-149) against the oracle's GRBCM.aggregate
+    fed with the same per-expert device means / variances; (ii) every expert's factor solves its system, K alpha = y at 1024 of its
+    own training points (PyGPR/gpr.py:65-85); (iii) positive variances below the prior's.  bench.py's grbcm_predict leg asserts the
+    same (bench.check_committee)."""
+    from bench import check_committee, synth_expert
+
+    nc, nls, ng, d, m = 8, 8192, 1024, 16, 8192
+    xg, yg = synth_expert(ng, d, 7)
+    sh = [synth_expert(nls, d, 100 + c) for c in range(nc)]
+    g4 = pg.GRBCM(T(np.stack([s[0] for s in sh])), T(np.stack([s[1] for s in sh])), T(xg), T(yg), se_wn())
+    hp = np.concatenate([[1.0], np.full(d, 0.5), [0.1]])
+    g4.set_params(T(hp))
+    xs = T(np.random.default_rng(4321).random((m, d)))
+    rep = check_committee(g4, xs, hp)
+    assert rep["experts_checked"] == nc and rep["batch"] == m
+    mu, var = g4.predict(xs, var="diag")
+    assert float(var.min()) > 0 and float(var.max()) < 1.0 + 0.01 + 1e-6      # prior variance sigma^2 + sigma_n^2
+    assert float((mu - T(np.sin(-N(xs).sum(1)))).abs().mean()) < 0.2            # and it predicts the function it was given
+    del g4
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_default_hp_gradient_error_is_stated(golden, capsys):
+    """Default hyper-parameters (sigma_n = 1e-4 + jitter 1e-7: cond(K) ~ 1e9): SURVEY 8c states NLML 1e-8 / gradient 1e-6 under the
+    rule |delta| <= 50 eps cond(K) |ref|.  The measured errors against the reference's own numbers are printed and asserted against
+    BOTH the rule (with cond(K) computed here) and the fixed 1e-6."""
+    g = golden("gp")
+    covs = [orc.SE, orc.WN]
+    rows = []
+    for tag in ("a", "b"):
+        x, y, hp0 = g[tag + "_x"], g[tag + "_y"], g[tag + "_hp0"]
+        k = orc.kernel(covs, hp0, x, form="direct") + 1e-7 * np.eye(x.shape[0])
+        cond = np.linalg.cond(k)
+        l0, g0 = pg.MLE(pg.Exact_GP(T(x), T(y), se_wn())).loss_and_grad(hp0.copy())
+        lref = g[tag + "_loss0"] if tag == "a" else np.array(-3461.42170686)
+        gref = g[tag + "_grad0"]
+        el = abs(float(l0) - float(lref)) / abs(float(lref))
+        eg = float(np.abs(g0 - gref).max() / np.abs(gref).max())
+        rule = 50 * np.finfo(np.float64).eps * cond
+        rows.append((tag, x.shape[0], cond, el, eg, rule))
+        assert el < 1e-8 and el <= rule, rows
+        assert eg <= rule, rows
+        assert eg < 1e-7, rows          # (SURVEY 8c's figure for this class is 1e-6)
+    with capsys.disabled():
+        for r in rows:
+            print("\n[default-hp parity] case %s n=%d cond(K)=%.2e  NLML rel err %.2e  grad err/|g|inf %.2e  (rule 50 eps cond = %.1e)" % r)

@@ -10,12 +10,12 @@ def ev(fn, reps=5):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
     return best
 k = ops.empty(n, n)
-for d in (1, 8, 16):
+for d in (8, 2, 16):
     rng = np.random.default_rng(d)
     x = torch.from_numpy(rng.random((n, d))).cuda()
     hp = torch.tensor([1.0] + [1.0] * d + [0.1], dtype=torch.float64).cuda()
-    for kind, name in ((0, "rbf"), (99, "noexp")):
+    for kind, name in ((0, "rbf"),):
         spec = make_spec([kind], [0], [d + 1])
         tl = ev(lambda: ops.kernel_build(spec, hp, x, None, k, lower_only=True, jitter=1e-7))
         tf = ev(lambda: ops.kernel_build(spec, hp, x, None, k, jitter=1e-7))
-        print(f"d={d:2d} {name:6s} lower {tl:.3f} ms  full(mirror) {tf:.3f} ms  {8*n*n/tf/1e6:.0f} GB/s", flush=True)
+        print(f"d={d:2d} {name:6s} lower {tl:.3f} ms {(4*n*(n+64)+8*n*d)/tl/1e6:.0f} GB/s   full(mirror) {tf:.3f} ms  {8*n*n/tf/1e6:.0f} GB/s", flush=True)
