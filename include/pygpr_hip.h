@@ -76,7 +76,7 @@ int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const d
 /* Lower Cholesky in place, replaces tc.cholesky (gpr.py:69, loss.py:39,64,97).  inv_diag is the factorisation's
  * workspace of pg_potrf_worksize(dtype, n) elements: its first n * 128 elements receive the inverses of the 128x128
  * diagonal blocks ([n/128][128][128]) that drive every later solve (pg_potrs_vec, pg_trtri ... only read that part);
- * the rest (64 n/128 + 2048 elements) is scratch of the call: the flag words through which the resident kernels of the coupled
+ * the rest (n + 2048 elements) is scratch of the call: the flag words through which the resident kernels of the coupled
  * chain hand over (csrc/chainstep.hip; zeroed by every call); with PG_PANEL_MODE=1 in the environment (experimental recursive
  * panel step) its buffers follow.
  * info: 0, or j + 1 when the leading minor of order j + 1 is not positive definite (LAPACK's convention), or -1 when a bounded

@@ -335,7 +335,7 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
     static const int direct = getenv("PG_CS_K128") ? atoi(getenv("PG_CS_K128")) : 1;
     hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
-                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (k0 / NB) : nullptr);
+                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr);
     PG_CHECK(hipGetLastError());
     return 0;
 }

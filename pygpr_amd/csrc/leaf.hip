@@ -72,6 +72,20 @@ __device__ __forceinline__ double inv_sqrt(double x) {
     r = r * (1.5 - 0.5 * x * r * r);
     return r;
 }
+// 1 / x to working precision: hardware seed + Newton (two steps in fp64, one in fp32)
+__device__ __forceinline__ double recip(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ float recip(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, y, 1.0f);
+    return __builtin_fmaf(y, e, y);
+}
 __device__ __forceinline__ float inv_sqrt(float x) {
     float r = __builtin_amdgcn_rsqf(x);
     r = r * (1.5f - 0.5f * x * r * r);
@@ -356,7 +370,8 @@ __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long ld
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool WT>   // WT: tile and inverse move with write-through / L1-bypassing accesses (the coupled chain)
 __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                           int* __restrict__ info, int col0, int ablate) {
+                                           int* __restrict__ info, int col0, int ablate, long long* tlog = nullptr) {
+#define LTL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((127 * lda + 128) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(inv, 0, inv ? (int)((127 * ldi + 128) * sizeof(T)) : 0, 0x00020000);
     T* S = reinterpret_cast<T*>(smem_raw);
@@ -368,28 +383,82 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
     if (*info != 0) return;
     if (tid == 0) fail = 0;
     typedef T pair_t __attribute__((ext_vector_type(2)));
-    {   // lower triangle -> LDS, two columns per thread, 64 pairs per row; all loads are issued before the first use
-        constexpr int NLD = (NB * NB / 2 + NTH - 1) / NTH;
-        pair_t v[NLD];
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
-            v[u] = pair_t{(T)0, (T)0};
-            if (idx < NB * NB / 2 && k <= i) {
-                if (WT) v[u] = ld_pair_wt(A, rA, (long)i * lda + k);
-                else v[u] = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
-            }
+    // ablate bit 4: the round-2 data movement (whole tile loaded before the first step, L and the inverse stored after the last)
+    const bool prog = !(ablate & 16);
+    // Tile -> LDS in two sets, all loads issued up front.  Set A = columns 0-31 (what the first micro-panel's step and its first
+    // update column touch) goes to LDS at once; set B = the rest is written behind the first step's barrier, so that its load
+    // latency (and 3/4 of the tile's bytes) hides behind that step instead of in front of it.
+    constexpr int NA = (NB * 16 + NTH - 1) / NTH, NBS = (NB * 48 + NTH - 1) / NTH;
+    pair_t va[NA], vb[NBS];
+    auto tile_load = [&](int i, int k) -> pair_t {
+        pair_t v = pair_t{(T)0, (T)0};
+        if (k <= i) {
+            if (WT) v = ld_pair_wt(A, rA, (long)i * lda + k);
+            else v = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
         }
+        return v;
+    };
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
-            if (k + 1 > i) v[u][1] = (T)0;
-            if (idx < NB * NB / 2) *reinterpret_cast<pair_t*>(S + i * LD + k) = v[u];
-        }
+    for (int u = 0; u < NA; ++u) {
+        const int idx = tid + u * NTH, i = idx >> 4, k = (idx & 15) * 2;
+        va[u] = (idx < NB * 16) ? tile_load(i, k) : pair_t{(T)0, (T)0};
     }
+#pragma unroll
+    for (int u = 0; u < NBS; ++u) {
+        const int idx = tid + u * NTH, i = idx / 48, k = (16 + idx % 48) * 2;
+        vb[u] = (idx < NB * 48) ? tile_load(i, k) : pair_t{(T)0, (T)0};
+    }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int idx = tid + u * NTH, i = idx >> 4, k = (idx & 15) * 2;
+        if (k + 1 > i) va[u][1] = (T)0;
+        if (idx < NB * 16) *reinterpret_cast<pair_t*>(S + i * LD + k) = va[u];
+    }
+    auto set_b_to_lds = [&]() {
+#pragma unroll
+        for (int u = 0; u < NBS; ++u) {
+            const int idx = tid + u * NTH, i = idx / 48, k = (16 + idx % 48) * 2;
+            if (k + 1 > i) vb[u][1] = (T)0;
+            if (idx < NB * 48) *reinterpret_cast<pair_t*>(S + i * LD + k) = vb[u];
+        }
+    };
+    if (!prog || (ablate & 1)) set_b_to_lds();
     __syncthreads();
+    LTL(16);
 
     const bool want_inv = inv != nullptr && !(ablate & 2);
+    // 16 columns of L (all 128 rows: zeros above the diagonal block) -> global, by the threads t0, t0 + nth, ...
+    auto store_l_panel = [&](int jbp, int t0, int nth) {
+        const int cc0 = 16 * jbp;
+        for (int idx = t0; idx < NB * 8; idx += nth) {
+            const int i = idx >> 3, k = cc0 + (idx & 7) * 2;
+            pair_t v = {(T)0, (T)0};
+            if (i >= cc0) v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+            if (k > i) v[0] = (T)0;                                                // right of the diagonal inside the diagonal block
+            if (k + 1 > i) v[1] = (T)0;
+            if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+            else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+        }
+    };
+    auto store_inv_rows = [&](int row_lo, int row_hi, int t0, int nth) {
+        for (int idx = row_lo * 64 + t0; idx < row_hi * 64; idx += nth) {
+            const int i = idx >> 6, k = (idx & 63) * 2;
+            const int pb = i >> 4, qb = k >> 4, ii = i & 15;
+            pair_t v = {(T)0, (T)0};
+            if (qb == pb) {
+                const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
+                v[0] = (k <= i) ? Dv[0] : (T)0;
+                v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
+            } else if (qb < pb) {
+                const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
+                v[0] = Xt[0];
+                v[1] = Xt[1];
+            }
+            if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
+            else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+        }
+    };
+    constexpr int STW = 7;                                  // waves STW .. NWV-1 never have a tile of the first update column (nt <= 7)
     for (int jb = 0; jb < ((ablate & 1) ? 0 : NB / 16); ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
         if (wave < NAB) {
@@ -407,32 +476,50 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
                 row[c] = (is_diag || is_panel) ? v : ((is_ident && c == pl) ? (T)1 : (T)0);
             }
             int first_bad = 16;
+            if (ablate & 32) {        // round 2's chain: 1 / sqrt(pivot) between two pivots
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const T piv = bcast_lane(row[c], c);                    // wave-uniform
-                first_bad = (piv > (T)0) ? first_bad : min(first_bad, c);
-                const T rs = inv_sqrt(piv);
-                const T lrc = row[c] * rs;
-                row[c] = lrc;
+                for (int c = 0; c < 16; ++c) {
+                    const T piv = bcast_lane(row[c], c);                    // wave-uniform
+                    first_bad = (piv > (T)0) ? first_bad : min(first_bad, c);
+                    const T rs = inv_sqrt(piv);
+                    const T lrc = row[c] * rs;
+                    row[c] = lrc;
 #pragma unroll
-                for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
+                    for (int k = c + 1; k < 16; ++k) row[k] -= lrc * bcast_lane(lrc, k);
+                }
+            } else {
+                // Square-root-free chain (L D L^T inside the micro-panel): between two pivots lie 1 / pivot (hardware seed + two
+                // Newton steps: four dependent operations against the seven of 1 / sqrt), one multiply and one update; the sixteen
+                // square roots follow afterwards, off the chain, as independent instruction streams.  Same numbers to rounding
+                // (tools/micro/tallstep.hip: 4.4e-16 against a long-double Cholesky for both forms; 1.44 -> 1.04 us per step).
+                //   u_rc = a_rc - sum_{j<c} u_rj u_cj / d_j,  d_c = u_cc,  L_rc = u_rc / sqrt(d_c)
+                T piv[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    piv[c] = bcast_lane(row[c], c);                         // wave-uniform
+                    first_bad = (piv[c] > (T)0) ? first_bad : min(first_bad, c);
+                    const T w = row[c] * recip(piv[c]);
+#pragma unroll
+                    for (int k = c + 1; k < 16; ++k) row[k] -= row[c] * bcast_lane(w, k);
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] *= inv_sqrt(piv[c]);
             }
             if (first_bad < 16) {                                        // wave-uniform (piv is)
                 if (wave == 0 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
-            } else if (is_diag) {
-                if (wave == 0) {
-                    T* D = S + (c0 + lane) * LD + c0;
+            } else {
+                // every lane that holds a real row writes it back whole: the four waves' copies of the diagonal rows are the same
+                // bits (same instructions on the same data), and what a diagonal row carries right of the diagonal is masked
+                // where L leaves the workgroup (nothing in LDS reads it) -- one store block instead of one per kind of lane
+                if (is_diag || is_panel) {
+                    T* P = S + (is_diag ? c0 + lane : prow) * LD + c0;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) D[c] = (c <= lane) ? row[c] : (T)0;
+                    for (int c = 0; c < 16; ++c) P[c] = row[c];
+                } else if (is_ident) {
+                    T* dst = Dinv + jb * 16 * DLD + pl;                  // column pl of D^-1
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) dst[c * DLD] = row[c];
                 }
-            } else if (is_panel) {
-                T* P = S + prow * LD + c0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) P[c] = row[c];
-            } else if (is_ident) {
-                T* dst = Dinv + jb * 16 * DLD + pl;                      // column pl of D^-1
-#pragma unroll
-                for (int c = 0; c < 16; ++c) dst[c * DLD] = row[c];
             }
         } else if (jb > 0) {
             // ---- deferred part of the previous trailing update: tiles (ti, tj) with 1 <= tj <= ti; then block row
@@ -461,9 +548,19 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
                     if (last) inv_tile_sum<T>(S, Dinv, jb, t - nrest, lane);
                 }
             }
+            // ---- then, still beside the tall-panel step (the longer half of this phase), these waves send out what the PREVIOUS
+            // step made final: its 16 columns of L and block row jb - 2 of the inverse.  Nothing reads or writes those again
+            // except the reads of later updates, so after the last step only that step's own columns and two block rows of the
+            // inverse are left to store.  (Stores placed in the short update phase behind the barrier stretched every step.)
+            if (prog) {
+                store_l_panel(jb - 1, tid - 64 * NAB, NTH - 64 * NAB);
+                if (want_inv && jb >= 2) store_inv_rows(16 * (jb - 2), 16 * (jb - 1), tid - 64 * NAB, NTH - 64 * NAB);
+            }
         }
         __syncthreads();
+        LTL(17 + 2 * jb);
         if (fail) return;
+        if (prog && jb == 0) set_b_to_lds();     // columns 32-127: nothing has touched them yet; the next barrier publishes them
         if (r0 >= NB) break;
         const int nt = (NB - r0) / 16;
         // ---- first tile column of the trailing update: next diagonal block and next panel, T <- T - P P^T
@@ -471,40 +568,39 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
             lds_tile_mm<T, true>(S + (r0 + t * 16) * LD + r0, LD, S + (r0 + t * 16) * LD + c0, LD, S + r0 * LD + c0, LD, 16,
                                  (T)-1, (T)1, lane);
         __syncthreads();
+        LTL(18 + 2 * jb);
     }
 
-    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
-        const int i = idx >> 6, k = (idx & 63) * 2;
-        pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
-        if (k > i) v[0] = (T)0;
-        if (k + 1 > i) v[1] = (T)0;
-        if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
-        else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
-    }
-    if (!want_inv) return;
-    auto store_inv_rows = [&](int row_lo, int row_hi) {
-        for (int idx = row_lo * 64 + tid; idx < row_hi * 64; idx += NTH) {
+    if (!prog || (ablate & 1)) {
+        for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
             const int i = idx >> 6, k = (idx & 63) * 2;
-            const int pb = i >> 4, qb = k >> 4, ii = i & 15;
-            pair_t v = {(T)0, (T)0};
-            if (qb == pb) {
-                const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
-                v[0] = (k <= i) ? Dv[0] : (T)0;
-                v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
-            } else if (qb < pb) {
-                const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
-                v[0] = Xt[0];
-                v[1] = Xt[1];
-            }
-            if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
-            else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+            pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+            if (k > i) v[0] = (T)0;
+            if (k + 1 > i) v[1] = (T)0;
+            if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+            else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
         }
-    };
-    store_inv_rows(0, 112);
-    if (ablate & 1) return;
-    for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);   // sums and Dinv[7] are in place (last step)
+        if (!want_inv) return;
+        store_inv_rows(0, 112, tid, NTH);
+        if (ablate & 1) return;
+        for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);   // sums and Dinv[7] are in place (last step)
+        __syncthreads();
+        store_inv_rows(112, 128, tid, NTH);
+        return;
+    }
+    // progressive form: the last step's columns of L, block row 6 of the inverse (final since the loop's last barrier) and, once
+    // its seven products are done, block row 7
+    if (want_inv && wave < 7) inv_tile_finish<T>(S, Dinv, 7, wave, lane);
+    if (wave >= STW) {
+        store_l_panel(NB / 16 - 1, tid - 64 * STW, NTH - 64 * STW);
+        if (want_inv) store_inv_rows(96, 112, tid - 64 * STW, NTH - 64 * STW);
+    }
+    (void)STW;
+    if (!want_inv) return;
     __syncthreads();
-    store_inv_rows(112, 128);
+    LTL(34);
+    store_inv_rows(112, 128, tid, NTH);
+#undef LTL
 }
 
 template <typename T>
@@ -521,7 +617,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long l
 // *done is set on every path (bad pivot, earlier failure, timeout): the rows below wait for it.
 template <typename T, bool WT>
 __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
-                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog) {
+                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
@@ -533,7 +629,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
     }
     __syncthreads();
     if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
-    leaf2_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, 0);
+    leaf2_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, ablate, tlog);
     if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -559,10 +655,19 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
         attr_done = true;
     }
     static const int wt = getenv("PG_CS_LEAF_WT") ? atoi(getenv("PG_CS_LEAF_WT")) : 1;
+    // Round 3 built two variants of the leaf's body and measured them against round 2's (same box, tools/probe_potrf_only.py and
+    // the in-kernel stamps of tools/probe_cs_tlog.py); round 2's form stays the default, the variants are kept behind switches:
+    //   PG_LEAF_PROG=1  tile loaded in two sets (columns 0-31 first), L columns and inverse block rows stored while the loop runs:
+    //                   load 2.2 -> 1.5 us, but the stores' LDS reads stretch every step by 0.1-0.3 us: n = 4096 1.63 -> 1.65 ms
+    //   PG_LEAF_LDL=1   square-root-free pivot chain (1.44 -> 1.04 us per 16-column step in isolation, tools/micro/tallstep.hip),
+    //                   no gain inside the kernel: a step's 2.9-3.5 us are the chain (1.4), the rows' LDS round trip (1.2) and
+    //                   two barriers, and the shorter chain only moves the waiting: n = 4096 1.63 -> 1.69 ms
+    static const int abl = ((getenv("PG_LEAF_PROG") && atoi(getenv("PG_LEAF_PROG"))) ? 0 : 16) |
+                           ((getenv("PG_LEAF_LDL") && atoi(getenv("PG_LEAF_LDL"))) ? 0 : 32);
     if (wt) hipLaunchKernelGGL((pg_leaf2s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
-                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (col0 / NB) : nullptr);
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr, abl);
     else hipLaunchKernelGGL((pg_leaf2s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
-                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 16 * (col0 / NB) : nullptr);
+                               getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr, abl);
     PG_CHECK(hipGetLastError());
     return 0;
 }
@@ -573,6 +678,8 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     static const int form = getenv("PG_LEAF") ? atoi(getenv("PG_LEAF")) : 2;   // 1: round-1 leaf (A / B / C phases), 2: fused tall-panel step
+    if (!(getenv("PG_LEAF_PROG") && atoi(getenv("PG_LEAF_PROG")))) ablate ^= 16;     // default: round 2's data movement (bit 4 set);
+    if (!(getenv("PG_LEAF_LDL") && atoi(getenv("PG_LEAF_LDL")))) ablate ^= 32;       // a caller's bit asks for the other form
     if (!attr_done) {
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

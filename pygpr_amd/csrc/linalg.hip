@@ -381,14 +381,14 @@ template <typename T> static GemmP<T> gp0() {
 // inv_diag [n/128][128][128], then the flag words of the coupled chain (3 n/128 + 1 ints, and the in-kernel time log when
 // PG_CS_TLOG is set), then -- only in the experimental recursive-panel mode (PG_PANEL_MODE=1) -- the work area of the panel step:
 // W = inverse of the current outer panel's triangular factor (at most 2048 x 2048) and Xs = the panel's solved rows before they
-// are copied back (n x at most 2048).  The default mode's workspace is n * 128 + 64 n/128 + 2048 elements (round 2 always
+// are copied back (n x at most 2048).  The default mode's workspace is n * 128 + 128 n/128 + 2048 elements (round 2 always
 // carried W and Xs: +300 MB at n = 16384, 35x the default need of a 2048-point expert).
 #define NBO_MAX 2048
 static int pg_panel_mode_env() {
     static const int v = getenv("PG_PANEL_MODE") ? atoi(getenv("PG_PANEL_MODE")) : 0;
     return v;
 }
-static long pg_flag_elems(int n) { return 64L * (n / NB) + 2048; }   // elements of T (>= 4 bytes each)
+static long pg_flag_elems(int n) { return 128L * (n / NB) + 2048; }   // elements of T (>= 4 bytes each)
 long pg_potrf_worksize_impl(int n) {
     const long w = std::min<long>(n, NBO_MAX);
     return (long)n * NB + pg_flag_elems(n) + (pg_panel_mode_env() == 1 ? w * w + (long)n * w : 0);

@@ -36,8 +36,8 @@ def test_library_loads_and_exports_every_header_symbol():
         assert isinstance(getattr(lib, n), ctypes._CFuncPtr)
     assert lib.pg_version() == 100
     # inv_diag + the coupled chain's flag words (the panel-mode buffers only exist with PG_PANEL_MODE=1)
-    assert lib.pg_potrf_worksize(0, 512) == 512 * 128 + 64 * 4 + 2048
-    assert lib.pg_potrf_worksize(0, 16384) == 16384 * 128 + 64 * 128 + 2048
+    assert lib.pg_potrf_worksize(0, 512) == 512 * 128 + 512 + 2048
+    assert lib.pg_potrf_worksize(0, 16384) == 16384 * 128 + 16384 + 2048
 
 
 def test_no_cpu_fallback_without_a_gpu():

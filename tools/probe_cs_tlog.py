@@ -19,10 +19,9 @@ for _ in range(3):
     ops.kernel_build(spec, hp, x, None, kl, lower_only=True, jitter=1e-7); ops.potrf(kl, invd, info)
     torch.cuda.synchronize()
 nblk = n // 128
-w = min(n, 2048)
-base = n * 128 + w * w                      # doubles: start of the flag words
+base = n * 128                              # doubles: start of the flag words (right behind the diagonal-block inverses)
 tmo_off_bytes = base * 8 + 3 * nblk * 4
-tl = invd.view(torch.int64)[(tmo_off_bytes // 8) + 512: (tmo_off_bytes // 8) + 512 + 16 * nblk].cpu().numpy().reshape(nblk, 16)
+tl = invd.view(torch.int64)[(tmo_off_bytes // 8) + 512: (tmo_off_bytes // 8) + 512 + 48 * nblk].cpu().numpy().reshape(nblk, 48)
 # wall_clock64: 100 MHz
 t0 = tl[0, 0]
 us = lambda v: (v - t0) / 100.0
@@ -33,3 +32,21 @@ for k in range(1, min(nblk - 1, 14)):
         k, us(L[0]), (L[1] - L[0]) / 100, (L[2] - L[1]) / 100, (L[3] - L[2]) / 100,
         (L[5] - L[3]) / 100, (L[6] - L[5]) / 100, (L[7] - L[6]) / 100, (L[8] - L[7]) / 100, (L[9] - L[8]) / 100, (L[10] - L[9]) / 100,
         (tl[k + 1][1] - L[10]) / 100))
+
+print("leaf phases (us): load | per micro-panel: step (tall panel + deferred/inverse), first update column | tail to body-end")
+for k in range(1, min(nblk - 1, 10)):
+    L = tl[k]
+    parts = ["load %.1f" % ((L[16] - L[1]) / 100)]
+    prev = L[16]
+    for jb in range(8):
+        a = L[17 + 2 * jb]
+        b = L[18 + 2 * jb] if jb < 7 else a
+        parts.append("%d: %.2f+%.2f" % (jb, (a - prev) / 100, (b - a) / 100))
+        prev = b
+    parts.append("finish %.2f, last stores %.2f" % ((L[34] - prev) / 100, (L[2] - L[34]) / 100))
+    print("%3d " % k + " | ".join(parts))
+
+for k in range(1, 4):
+    L = tl[k]
+    print("%3d step 3 of the leaf, wave 0: previous barrier -> phase start %.2f | LDS reads %.2f | 16-column loop %.2f | LDS writes %.2f | barrier wait %.2f" % (
+        k, (L[35] - L[18 + 2 * 2]) / 100, (L[36] - L[35]) / 100, (L[37] - L[36]) / 100, (L[38] - L[37]) / 100, (L[17 + 2 * 3] - L[38]) / 100))

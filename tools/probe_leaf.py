@@ -17,7 +17,7 @@ def run(ablate, with_inv=True):
     for b in range(nb): ops.leaf_raw(a[b], inv[b] if with_inv else None, info, ablate)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / nb * 1e3
-for name, ab, wi in [("full", 0, True), ("no inverse", 2, True), ("no factor loop (I/O + tail of the inverse)", 1, True),
+for name, ab, wi in [("full", 0, True), ("full, progressive loads/stores", 16, True), ("full, square-root-free chain", 32, True), ("full, both", 48, True),  ("no inverse", 2, True), ("no factor loop (I/O + tail of the inverse)", 1, True),
                      ("no factor loop, no inverse (I/O + launch only)", 3, True), ("no diagonal step (A)", 8, True),
                      ("no A, no inverse", 10, True)]:
     run(ab, wi); t = min(run(ab, wi) for _ in range(3))
