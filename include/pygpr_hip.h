@@ -109,6 +109,17 @@ int pg_build_potrf_trtri_checked(pg_handle h, int dtype, const pg_covspec* spec,
                                  int d, double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
                                  void* stream, int* info_host);
 
+/* Batched experts: nexp independent problems of the same size in ONE call -- the leading batch dimension of the reference's
+ * Exact_GP (gpr.py:65-74 factorises all experts of a GRBCM in one batched tc.cholesky, gr_bcm.py:19-29).  Expert e uses
+ * hp + e * hp_stride, X + e * x_stride (a stride of 0 shares the points), A + e * a_stride, inv_diag + e * inv_stride
+ * (inv_stride >= pg_potrf_worksize), info[e], Minv + e * m_stride (Minv may be NULL: factor only).  X == NULL: A already holds
+ * the matrices (lower triangles).  Every launch of the blocked algorithm covers all experts (grid.y = expert), so the latency-bound
+ * 128-column steps of the chain cost one launch triple per batch instead of one per expert; the per-expert numbers are those of
+ * pg_build_potrf_trtri on the classic chain, bit for bit. */
+int pg_build_potrf_trtri_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* X, long ldx,
+                                 long x_stride, int n, int d, double jitter, void* A, long lda, long a_stride, int n_pad, void* inv_diag,
+                                 long inv_stride, int* info, void* Minv, long ldm, long m_stride, int nexp, void* stream);
+
 /* x = K^-1 y from the factor: the cholesky_solve of gpr.py:70-72 / loss.py:45.  y is not modified;
  * work: pg_potrs_vec_worksize(dtype, n) elements (2 n below n = 2048; above, also the 1024-wide diagonal block
  * inverses the blocked sweeps multiply with). */
@@ -136,6 +147,11 @@ int pg_logdet(pg_handle h, int dtype, int n, const void* L, long ldl, double* ou
 /* y = op(Minv) x for the lower-triangular Minv (trans: 0 = Minv x, 1 = Minv^T x); work: n/256*n elems */
 int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans, const void* x, void* y,
             void* work, void* stream);
+
+/* alpha_e = Minv_e^T (Minv_e y_e) for nexp batched experts in three launches (the cholesky_solve of gpr.py:70-72 through the explicit
+ * inverse factors of pg_build_potrf_trtri_batched); u: n and work: (n/256) n scratch elements per expert, each with its stride. */
+int pg_alpha_batched(pg_handle h, int dtype, int n, const void* Minv, long ldm, long m_stride, const void* y, long y_stride, void* u,
+                     long u_stride, void* alpha, long alpha_stride, void* work, long work_stride, int nexp, void* stream);
 
 /* out[0] = 1/2 y^T alpha + sum_i log L_ii + n/2 log 2pi   (loss.py:47-49, 107-109); n = real points */
 int pg_nlml_value(pg_handle h, int dtype, int n, const void* L, long ldl, const void* y, const void* alpha,

@@ -69,6 +69,9 @@ _SIGS = {
     "pg_build_potrf_trtri": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _d, _vp, _l, _i, _vp, _vp, _vp, _l, _vp]),
     "pg_build_potrf_trtri_checked": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _d, _vp, _l, _i, _vp, _vp, _vp, _l, _vp,
                                           C.POINTER(_i)]),
+    "pg_build_potrf_trtri_batched": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _l, _vp, _l, _l, _i, _i, _d, _vp, _l, _l, _i, _vp, _l, _vp, _vp,
+                                          _l, _l, _i, _vp]),
+    "pg_alpha_batched": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _vp]),
     "pg_set_spin_budget": (_i, [_vp, _l]),
     "pg_chain_timeouts": (_i, [_vp]),
     "pg_last_coupled_panels": (_i, [_vp]),

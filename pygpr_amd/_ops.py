@@ -111,8 +111,11 @@ class HipOps:
         return self.kernel_build(spec, ones, xr, xc, out)
 
     # -- factorisation and solves -------------------------------------------------------------
+    def potrf_worksize(self, n_pad, dtype):
+        return int(self.lib.pg_potrf_worksize(_code(dtype), n_pad))
+
     def potrf_workspace(self, n_pad, dtype):
-        return self.empty(self.lib.pg_potrf_worksize(_code(dtype), n_pad), dtype=dtype)
+        return self.empty(self.potrf_worksize(n_pad, dtype), dtype=dtype)
 
     def potrf(self, a, invd, info):
         self._chk(a, invd, info)
@@ -134,6 +137,31 @@ class HipOps:
             self.h, _code(a.dtype), C.byref(passes[0]), _p(hp), _p(x), x.stride(0), n, d, float(jitter), _p(a), a.stride(0),
             a.shape[0], _p(invd), _p(info), _p(minv), minv.stride(0) if minv is not None else 0, self._st()),
             "pg_build_potrf_trtri")
+
+    def build_factor_batched(self, spec, hp_all, x_all, x_stride, a_all, invd_all, info_all, minv_all=None, jitter=JITTER):
+        """The same for nexp experts of one size in ONE call (pg_build_potrf_trtri_batched): hp_all [nexp, nhp], x_all [nexp | 1, n, d]
+        (x_stride = 0 shares the points), a_all [nexp, n_pad, n_pad], invd_all [nexp, pg_potrf_worksize], info_all [nexp] int32,
+        minv_all [nexp, n_pad, n_pad] or None.  Every launch covers all experts; classic chain."""
+        passes = _passes(spec)
+        assert len(passes) == 1
+        self._chk(hp_all, x_all, a_all, invd_all, info_all, minv_all)
+        assert hp_all.dtype == torch.float64 and info_all.dtype == torch.int32
+        nexp, n_pad = a_all.shape[0], a_all.shape[1]
+        n, d = x_all.shape[-2], x_all.shape[-1]
+        _lib.check(self.lib.pg_build_potrf_trtri_batched(
+            self.h, _code(a_all.dtype), C.byref(passes[0]), _p(hp_all), hp_all.stride(0), _p(x_all), x_all.stride(-2), int(x_stride),
+            n, d, float(jitter), _p(a_all), a_all.stride(1), a_all.stride(0), n_pad, _p(invd_all), invd_all.stride(0), _p(info_all),
+            _p(minv_all), minv_all.stride(1) if minv_all is not None else 0, minv_all.stride(0) if minv_all is not None else 0,
+            nexp, self._st()), "pg_build_potrf_trtri_batched")
+
+    def alpha_batched(self, minv_all, y_all, u_all, alpha_all, work_all):
+        """alpha_e = minv_e^T (minv_e y_e) for all experts in three launches; y_all [nexp | 1, n_pad] (one row: shared targets),
+        u_all [nexp, n_pad], work_all [nexp, (n_pad/256) n_pad]."""
+        self._chk(minv_all, y_all, u_all, alpha_all, work_all)
+        _lib.check(self.lib.pg_alpha_batched(self.h, _code(minv_all.dtype), minv_all.shape[1], _p(minv_all), minv_all.stride(1),
+                                             minv_all.stride(0), _p(y_all), y_all.stride(0) if y_all.shape[0] > 1 else 0, _p(u_all), u_all.stride(0), _p(alpha_all),
+                                             alpha_all.stride(0), _p(work_all), work_all.stride(0), minv_all.shape[0], self._st()),
+                   "pg_alpha_batched")
 
     def potrf_trtri(self, a, invd, info, minv):
         """Cholesky in place + minv = L^-1, fused so that part of the inverse overlaps the factorisation's tail."""

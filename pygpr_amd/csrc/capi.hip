@@ -126,6 +126,7 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     p.alpha = (T)alpha; p.beta = (T)beta;
     p.tri = tri; p.klo = klo; p.khi = khi;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
+    p.nexp = 1; p.eA = p.eB = p.eC = 0; p.einfo = 0;
     p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
     // PG_RAW_STREAM=upd|bg (measurement only): run the product on one of the handle's CU-masked streams instead
     static const char* rs = getenv("PG_RAW_STREAM");
@@ -182,6 +183,17 @@ static int build_potrf_t(pg_handle h, hipStream_t st, const pg_covspec* spec, co
     BuildReq<T> br;
     br.spec = spec; br.hp = hp; br.X = (const T*)X; br.ldx = ldx; br.n_real = n; br.d = d; br.jitter = jitter;
     return pg_potrf_t<T>(h, st, n_pad, (T*)A, lda, (T*)inv_diag, info, (T*)Minv, ldm, &br);
+}
+
+template <typename T>
+static int potrf_batched_t(pg_handle h, hipStream_t st, const pg_covspec* spec, const double* hp, long hp_stride, const void* X, long ldx,
+                           long x_stride, int n, int d, double jitter, void* A, long lda, long a_stride, int n_pad, void* inv_diag,
+                           long inv_stride, int* info, void* Minv, long ldm, long m_stride, int nexp) {
+    ExpBatch eb;
+    eb.nexp = nexp; eb.eA = a_stride; eb.eInv = inv_stride; eb.eM = m_stride; eb.eX = x_stride; eb.ehp = hp_stride;
+    BuildReq<T> br;
+    br.spec = spec; br.hp = hp; br.X = (const T*)X; br.ldx = ldx; br.n_real = n; br.d = d; br.jitter = jitter;
+    return pg_potrf_t<T>(h, st, n_pad, (T*)A, lda, (T*)inv_diag, info, (T*)Minv, ldm, X ? &br : nullptr, &eb);
 }
 
 extern "C" {
@@ -349,6 +361,27 @@ int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const d
              build_potrf_t<float>(h, ST(stream), spec, hp, X, ldx, n, d, jitter, A, lda, n_pad, inv_diag, info, Minv, ldm));
 }
 
+int pg_build_potrf_trtri_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* X, long ldx,
+                                 long x_stride, int n, int d, double jitter, void* A, long lda, long a_stride, int n_pad, void* inv_diag,
+                                 long inv_stride, int* info, void* Minv, long ldm, long m_stride, int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && A && inv_diag && info, "null pointer");
+    NEED(!X || hp, "a folded build needs hp");
+    if (X && check_spec(spec, __func__, true)) return -1;
+    NEED(nexp >= 1 && nexp <= 65535, "1 <= nexp <= 65535");
+    NEED(n >= 0 && n_pad >= n && lda >= n_pad, "inconsistent sizes");
+    NEED(a_stride >= (long)n_pad * lda || nexp == 1, "experts' matrices overlap");
+    NEED(inv_stride >= pg_potrf_worksize_impl(n_pad) || nexp == 1, "experts' workspaces overlap (stride < pg_potrf_worksize)");
+    NEED(!Minv || (ldm >= n_pad && (m_stride >= (long)n_pad * ldm || nexp == 1)), "experts' inverses overlap");
+    NEED(lda % (dtype == PG_F64 ? 2 : 4) == 0, "lda must keep rows 16-byte aligned");
+    AtomicGuard ag(h, A);
+    DISPATCH(dtype,
+             potrf_batched_t<double>(h, ST(stream), spec, hp, hp_stride, X, ldx, x_stride, n, d, jitter, A, lda, a_stride, n_pad, inv_diag,
+                                     inv_stride, info, Minv, ldm, m_stride, nexp),
+             potrf_batched_t<float>(h, ST(stream), spec, hp, hp_stride, X, ldx, x_stride, n, d, jitter, A, lda, a_stride, n_pad, inv_diag,
+                                    inv_stride, info, Minv, ldm, m_stride, nexp));
+}
+
 long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize_impl(n); }
 
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
@@ -428,6 +461,18 @@ int pg_trmv(pg_handle h, int dtype, int n, const void* Minv, long ldm, int trans
     DISPATCH(dtype,
              pg_trmv_t<double>(h, ST(stream), n, (const double*)Minv, ldm, trans, (const double*)x, (double*)y, (double*)work),
              pg_trmv_t<float>(h, ST(stream), n, (const float*)Minv, ldm, trans, (const float*)x, (float*)y, (float*)work));
+}
+
+int pg_alpha_batched(pg_handle h, int dtype, int n, const void* Minv, long ldm, long m_stride, const void* y, long y_stride, void* u,
+                     long u_stride, void* alpha, long alpha_stride, void* work, long work_stride, int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Minv && y && u && alpha && work, "null pointer");
+    NEED(ldm >= n && nexp >= 1 && nexp <= 65535, "bad size");
+    DISPATCH(dtype,
+             pg_alpha_batched_t<double>(ST(stream), n, (const double*)Minv, ldm, m_stride, (const double*)y, y_stride, (double*)u, u_stride,
+                                        (double*)alpha, alpha_stride, (double*)work, work_stride, nexp),
+             pg_alpha_batched_t<float>(ST(stream), n, (const float*)Minv, ldm, m_stride, (const float*)y, y_stride, (float*)u, u_stride,
+                                       (float*)alpha, alpha_stride, (float*)work, work_stride, nexp));
 }
 
 int pg_alpha_nlml_async(pg_handle h, int dtype, int n_real, int n, const void* L, long ldl, const void* Minv, long ldm, const void* y,

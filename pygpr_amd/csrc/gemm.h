@@ -16,8 +16,11 @@ template <typename T> struct GemmP {
     T alpha, beta;
     int tri;          // 1: only tiles on or below the diagonal (BM == BN)
     int klo, khi;     // K-range from a triangular operand: 0 none, 1 follows the tile row, 2 the tile column
-    long sA, sB, sC;  // batch strides (elements), grid.y = batch
+    long sA, sB, sC;  // batch strides (elements), grid.y = batch * nexp
     int batch;
+    int nexp;         // independent problems of the same shape in one launch (batched experts): z = blockIdx.y -> (z % batch, z / batch)
+    long eA, eB, eC;  // their strides (elements)
+    int einfo;        // stride of `info` between them (0: one shared flag)
     T* part;          // EPI == 1: partial column sums of squares, [M/64][ldp]
     long ldp;
     const int* info;  // device flag: kernels exit at once when *info != 0 (failed factorisation)

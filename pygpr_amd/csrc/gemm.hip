@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
     constexpr int WN_ = BN / WTN;                             // waves along N
     static_assert((BM / WTM) * (BN / WTN) == NW, "the waves must tile the block");
 
-    if (p.info && *p.info != 0) return;
+    const int ze = (int)blockIdx.y / p.batch;                      // which of the batched problems (experts)
+    if (p.info && p.info[(long)ze * p.einfo] != 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* As = reinterpret_cast<T*>(smem_raw);
     T* Bs = As + 2 * SA::LDS_ELEMS;
@@ -144,10 +145,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
         tj = wg % tn;
         if (p.khi == 1) ti = p.M / BM - 1 - ti;   // K grows with the tile row: launch the long rows first
     }
-    const long zb = blockIdx.y;
-    const T* __restrict__ A = p.A + zb * p.sA;
-    const T* __restrict__ B = p.B + zb * p.sB;
-    T* __restrict__ C = p.C ? p.C + zb * p.sC : nullptr;
+    const long zb = (int)blockIdx.y % p.batch;
+    const T* __restrict__ A = p.A + zb * p.sA + ze * p.eA;
+    const T* __restrict__ B = p.B + zb * p.sB + ze * p.eB;
+    T* __restrict__ C = p.C ? p.C + zb * p.sC + ze * p.eC : nullptr;
 
     const int m0 = ti * BM, n0 = tj * BN;
     int kbeg = 0, kend = p.K;
@@ -269,8 +270,8 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
     }
     const int tm = p.M / BM, tn = p.N / BN;
     const long tiles = p.tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
-    if (tiles == 0 || p.batch == 0) return 0;
-    dim3 grid((unsigned)tiles, (unsigned)p.batch, 1);
+    if (tiles == 0 || p.batch == 0 || p.nexp == 0) return 0;
+    dim3 grid((unsigned)tiles, (unsigned)(p.batch * p.nexp), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
     PG_CHECK(hipGetLastError());
     return 0;
@@ -307,6 +308,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     const bool w4 = w4env || sizeof(T) == 4 || ((variant == GEMM_NN_128_SS || variant == GEMM_NT_128_SS) && ss4);
     GemmP<T> p = p_in;
     p.noxcd = noxcd;
+    if (p.nexp < 1) p.nexp = 1;
     static const int atomic_c = getenv("PG_ATOMIC_C") ? atoi(getenv("PG_ATOMIC_C")) : 1;   // 0: read-modify-write epilogue
     p.atomic_c = (atomic_c && !(ctx && ctx->no_atomic_c) && sizeof(T) == 8 && p.beta == (T)1 && p.C && p.part == nullptr) ? 1 : 0;
     const bool prof = ctx && ctx->prof_on;
@@ -335,7 +337,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         static FILE* logf = getenv("PG_GEMM_LOG") ? fopen(getenv("PG_GEMM_LOG"), "w") : nullptr;
         if (logf) {
             fprintf(logf, "%d %d %d %d %d %d %d %.0f\n", variant, (int)sizeof(T), w4 ? 4 : 8, p.M, p.N, p.K, p.batch,
-                    pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch));
+                    pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch * p.nexp));
             fflush(logf);
         }
     }
@@ -345,7 +347,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         float ms = 0;
         PG_CHECK(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
         ctx->prof_ms += ms;
-        ctx->prof_flops += pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch);
+        ctx->prof_flops += pg_gemm_flops(variant, p.M, p.N, p.K, p.tri, p.klo, p.khi, p.batch * p.nexp);
         ctx->prof_launches += 1;
     }
     return 0;

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                                                         const T* __restrict__ Xr, long ldr, int nr,
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
                                                         int symmetric, int accumulate, double jitter,
-                                                        T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int sq_grid) {
+                                                        T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int sq_grid,
+                                                        long eX, long ehp, long eK) {
+    // batched experts (symmetric builds): blockIdx.y = expert, each with its own points, hyper-parameters and matrix
+    Xr += blockIdx.y * eX; Xc += blockIdx.y * eX; hp += blockIdx.y * ehp; K += blockIdx.y * eK;
     int tr, tc;
     kb_tile_of(blockIdx.x, symmetric && !sq_grid, ctile0, ctile1, tr, tc);
     if (sq_grid && symmetric && tc > tr) return;    // PG_KB_GRID2D=1 (experiment): round 2's full-square grid
@@ -245,7 +248,8 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
               const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,
-              long ldk, int rows_pad, int cols_pad, int col0, int col1) {
+              long ldk, int rows_pad, int cols_pad, int col0, int col1, int nexp, long eX, long ehp, long eK) {
+    if (nexp > 1 && !symmetric) { pg_set_error("pg_kbuild: only symmetric builds are batched"); return -2; }
     if (rows_pad % KT || cols_pad % KT || d < 1 || d > PG_MAX_DIM) {
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
@@ -282,18 +286,18 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
     static const int presc_env = getenv("PG_KB_PRESC") ? atoi(getenv("PG_KB_PRESC")) : 1;
     const int presc = (presc_env && spec.ncomp == 1) ? 1 : 0;
     if (mirror)
-        hipLaunchKernelGGL((pg_kbuild_kernel<T, true>), dim3((unsigned)tiles), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid);
+        hipLaunchKernelGGL((pg_kbuild_kernel<T, true>), dim3((unsigned)tiles, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
+                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid, eX, ehp, eK);
     else
-        hipLaunchKernelGGL((pg_kbuild_kernel<T, false>), dim3((unsigned)tiles), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid);
+        hipLaunchKernelGGL((pg_kbuild_kernel<T, false>), dim3((unsigned)tiles, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
+                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid, eX, ehp, eK);
     PG_CHECK(hipGetLastError());
     return 0;
 }
 template int pg_kbuild<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int,
-                               const double*, long, int, int, int, int, int, double, double*, long, int, int, int, int);
+                               const double*, long, int, int, int, int, int, double, double*, long, int, int, int, int, int, long, long, long);
 template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int,
-                              const float*, long, int, int, int, int, int, double, float*, long, int, int, int, int);
+                              const float*, long, int, int, int, int, int, double, float*, long, int, int, int, int, int, long, long, long);
 
 // ------------------------------------------------------------------------------------------------
 // dK stack of the public Covar.kernel_and_grad (covar.py:64-81,169-206,247-269): dK[p][i][j] for

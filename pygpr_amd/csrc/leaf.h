@@ -3,7 +3,9 @@
 // Factor the 128x128 diagonal block A (lower Cholesky, in place) and, when inv != NULL, write its
 // inverse (lower, upper part zero) to inv.  *info (device) receives col0 + j + 1 on a bad pivot.
 // ablate != 0 skips phases (timing diagnostics only: bit 0 factor loop, 1 inverse, 3 diagonal step).
-template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate = 0);
+// nexp > 1: the same leaf of nexp batched problems in one launch (A + e * eA, inv + e * eInv, info[e]).
+template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate = 0, int nexp = 1,
+                                  long eA = 0, long eInv = 0);
 // The same leaf as one half of the flag-coupled chain (chainstep.hip): waits for *ready >= want, factors, sets *done.
 struct CsWait;
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,

@@ -212,7 +212,10 @@ __device__ __forceinline__ void row_solve16(T (&x)[16], const T* D, const T* rd)
 
 template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                                      int* __restrict__ info, int col0, int ablate) {
+                                                      int* __restrict__ info, int col0, int ablate, long eA, long eInv) {
+    A += blockIdx.x * eA;                     // batched experts: one workgroup each, one info word each
+    if (inv) inv += blockIdx.x * eInv;
+    info += blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* S = reinterpret_cast<T*>(smem_raw);
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
@@ -605,9 +608,10 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
 
 template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                                       int* __restrict__ info, int col0, int ablate) {
+                                                       int* __restrict__ info, int col0, int ablate, long eA, long eInv) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf2_body<T, false>(smem_raw, A, lda, inv, ldi, info, col0, ablate);
+    // batched experts: one workgroup each, one info word each
+    leaf2_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0, ablate);
 }
 
 // The leaf of the flag-coupled chain (chainstep.hip): resident before its tile exists.  Waits until the `want` workgroups that
@@ -674,7 +678,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
 template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&);
 template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&);
 
-template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate) {
+template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate, int nexp, long eA,
+                                  long eInv) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     static const int form = getenv("PG_LEAF") ? atoi(getenv("PG_LEAF")) : 2;   // 1: round-1 leaf (A / B / C phases), 2: fused tall-panel step
@@ -687,10 +692,10 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (form == 1) hipLaunchKernelGGL(pg_leaf_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
-    else hipLaunchKernelGGL(pg_leaf2_kernel<T>, dim3(1), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate);
+    if (form == 1) hipLaunchKernelGGL(pg_leaf_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate, eA, eInv);
+    else hipLaunchKernelGGL(pg_leaf2_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate, eA, eInv);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_leaf<double>(hipStream_t, double*, long, double*, long, int*, int, int);
-template int pg_leaf<float>(hipStream_t, float*, long, float*, long, int*, int, int);
+template int pg_leaf<double>(hipStream_t, double*, long, double*, long, int*, int, int, int, long, long);
+template int pg_leaf<float>(hipStream_t, float*, long, float*, long, int*, int, int, int, long, long);

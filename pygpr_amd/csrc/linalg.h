@@ -12,14 +12,26 @@ template <typename T> struct BuildReq {
     int n_real, d;
     double jitter;
 };
+// Batched experts: nexp independent problems of the same size in every launch of the call (A + e * eA, the workspace + e * eInv,
+// Minv + e * eM, info[e]; a folded build reads X + e * eX and hp + e * ehp).  The per-step launches of the latency-bound chain are
+// then paid once per batch instead of once per expert; the schedule is the classic chain (no flag-coupled kernels).
+struct ExpBatch {
+    int nexp;
+    long eA, eInv, eM, eX, ehp;
+};
 template <typename T>
-int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build = nullptr);
+int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build = nullptr,
+               const ExpBatch* eb = nullptr);
 template <typename T> int pg_potrs_vec_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work);
-template <typename T> int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0);
+template <typename T>
+int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0, const ExpBatch* eb = nullptr);
 long pg_potrs_vec_worksize_impl(int n);
 template <typename T> int pg_logdet_t(hipStream_t, int n, const T* L, long ldl, double* out);
 template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);
 template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work);
+template <typename T>
+int pg_alpha_batched_t(hipStream_t, int n, const T* M, long ldm, long eM, const T* y, long ey, T* u, long eu, T* alpha, long ea, T* work, long ew,
+                       int nexp);
 template <typename T>
 int pg_alpha_nlml_async_t(pg_ctx*, hipStream_t, int n_real, int n, const T* L, long ldl, const T* Minv, long ldm, const T* y, T* u,
                           T* alpha, T* work, double* out);

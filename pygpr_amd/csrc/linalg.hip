@@ -33,8 +33,10 @@ static int pg_nbo(const pg_ctx* ctx, int n) {
 // small kernels
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void copy_blocks_kernel(const T* __restrict__ src, T* __restrict__ dst, long ldd) {
-    // dst diagonal block b (128x128) <- src[b][128][128]
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const T* __restrict__ src, T* __restrict__ dst, long ldd, long esrc, long edst) {
+    // dst diagonal block b (128x128) <- src[b][128][128]   (blockIdx.z: batched expert)
+    src += blockIdx.z * esrc;
+    dst += blockIdx.z * edst;
     const int b = blockIdx.x;
     const T* s = src + (long)b * NB * NB;
     T* d = dst + (long)b * NB * ldd + (long)b * NB;
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const T* __restrict_
 // part[rc][j] = sum_{i in row chunk rc} A[i][j] x[i]; tri: skip chunks above the diagonal
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T* __restrict__ A, long lda, const T* __restrict__ x,
-                                                             T* __restrict__ part, long ldp, int tri) {
+                                                             T* __restrict__ part, long ldp, int tri, long eA = 0, long ex = 0, long ep = 0) {
+    A += blockIdx.z * eA; x += blockIdx.z * ex; part += blockIdx.z * ep;      // batched experts
     const int cc = blockIdx.x, rc = blockIdx.y;
     if (tri && rc < cc) return;
     __shared__ double xs[256];
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T* __restrict
 // out[j] = a + b * sum_{rc >= rc0(j)} part[rc][j]   (acc: out[j] += b * sum)
 template <typename T>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ part, long ldp, int nrc, int cols,
-                                                        T* __restrict__ out, int tri, double a, double b, int acc) {
+                                                        T* __restrict__ out, int tri, double a, double b, int acc, long ep = 0, long eo = 0) {
+    part += blockIdx.z * ep; out += blockIdx.z * eo;                          // batched experts
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cols) return;
     double s = 0.0;
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(256) void gemv_n_sub_kernel(const T* __restrict__ A
 // 16-byte loads, four independent partial sums per lane, and the long rows (bottom of the matrix) launched first.
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ M, long ldm, int n, const T* __restrict__ x,
-                                                     T* __restrict__ y) {
+                                                     T* __restrict__ y, long eM = 0, long ex = 0, long ey = 0) {
+    M += blockIdx.z * eM; x += blockIdx.z * ex; y += blockIdx.z * ey;         // batched experts
     constexpr int VE = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -374,6 +379,7 @@ template <typename T> static GemmP<T> gp0() {
     p.alpha = (T)1; p.beta = (T)0;
     p.tri = p.klo = p.khi = 0;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
+    p.nexp = 1; p.eA = p.eB = p.eC = 0; p.einfo = 0;
     p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
     return p;
 }
@@ -395,9 +401,11 @@ long pg_potrf_worksize_impl(int n) {
 }
 
 template <typename T>
-int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax) {
+int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax, const ExpBatch* eb) {
     if (n <= 0 || n % NB) { pg_set_error("pg_trtri: n=%d is not a positive multiple of %d", n, NB); return -2; }
-    hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 8), dim3(256), 0, st, invD, M, ldm);
+    const int nexp = eb ? eb->nexp : 1;
+    const long eL = eb ? eb->eA : 0, eI = eb ? eb->eInv : 0, eMm = eb ? eb->eM : 0;
+    hipLaunchKernelGGL(copy_blocks_kernel<T>, dim3(n / NB, 8, nexp), dim3(256), 0, st, invD, M, ldm, eI, eMm);
     LAUNCH_CHECK();
     // invariant: the diagonal is tiled by `nfull` inverted blocks of size h plus one smaller inverted block `rem`
     int rc;
@@ -421,6 +429,7 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
             p.C = M + r0 * ldm + r0 + h; p.ldc = ldm;
             p.klo = 1; p.batch = (int)batch;
             p.sA = stride; p.sC = stride; p.sB = 2 * h * (ldl + 1);
+            p.nexp = nexp; p.eA = eMm; p.eB = eL; p.eC = eMm;
             // few pairs of small blocks: 64 x 64 tiles give 4x the workgroups, each a quarter as long (h = 256: 42 -> 15 us)
             const bool small = batch * (h / 128) * (h2 / 128) <= 1024 && h2 % 64 == 0;   // swept 128 .. 4200
             if ((rc = pg_gemm<T>(ctx, st, small ? GEMM_TT_64 : GEMM_TT_128, p))) return rc;
@@ -432,6 +441,7 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
             p.C = M + (r0 + h) * ldm + r0; p.ldc = ldm;
             p.alpha = (T)-1; p.khi = 1; p.batch = (int)batch;
             p.sA = p.sB = p.sC = stride;
+            p.nexp = nexp; p.eA = p.eB = p.eC = eMm;
             if ((rc = pg_gemm<T>(ctx, st, small ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         if (nfull & 1) rem = rem ? h + rem : h;   // the odd block merges with rem, or becomes the new rem
@@ -482,9 +492,14 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
 // whole CU's LDS) always find free CUs instead of queueing behind 280 us SYRK tiles.  Everything is joined back onto
 // the caller's stream at the end.
 template <typename T>
-int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build) {
+int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build,
+               const ExpBatch* eb) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
-    PG_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
+    const int nexp = eb ? eb->nexp : 1;                       // batched experts: every launch below covers all of them
+    const long eA = eb ? eb->eA : 0, eI = eb ? eb->eInv : 0;
+    if (nexp < 1) { pg_set_error("pg_potrf: empty batch"); return -2; }
+    auto batched = [&](GemmP<T>& p, long sa, long sb, long sc) { p.nexp = nexp; p.eA = sa; p.eB = sb; p.eC = sc; p.einfo = nexp > 1 ? 1 : 0; };
+    PG_CHECK(hipMemsetAsync(info, 0, sizeof(int) * nexp, st));
     const int NBO = pg_nbo(ctx, n);
     // Outer panel boundaries (uniform; the last one may be short).  Measured on the round-2 build and left out: cutting the
     // first panel in two (256 + NBO - 256 columns) so that the first big update starts after two leaves instead of eight,
@@ -504,7 +519,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     static const int sync_env = getenv("PG_SYNC_ROWS") ? atoi(getenv("PG_SYNC_ROWS")) : -1;
     const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && ctx->bg && n > 8192) ? 0 : 8192);
     hipStream_t rows_stream = ctx->rows;      // the handle's own (capi.hip)
-    const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0;
+    const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0 && nexp == 1;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
     static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 512;
     for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, cs_panel) : NBO) pb.push_back(c);
@@ -520,7 +535,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     if (build) {
         const int c1 = build_split ? pb[1] : n;
         if ((rc = pg_kbuild<T>(st, *build->spec, build->hp, build->X, build->ldx, build->n_real, build->X, build->ldx, build->n_real,
-                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, 0, c1)))
+                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, 0, c1, nexp, eb ? eb->eX : 0, eb ? eb->ehp : 0, eA)))
             return rc;
     }
     if (la) {
@@ -531,7 +546,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     }
     if (build_split) {
         if ((rc = pg_kbuild<T>(us, *build->spec, build->hp, build->X, build->ldx, build->n_real, build->X, build->ldx, build->n_real,
-                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, pb[1], n)))
+                               build->d, 1, 1, 0, build->jitter, A, lda, n, n, pb[1], n, nexp, eb ? eb->eX : 0, eb ? eb->ehp : 0, eA)))
             return rc;
         if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;      // ev_build: every column right of the first panel exists
         PG_CHECK(hipEventRecord(ev, us));
@@ -539,7 +554,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // fused L^-1: split the diagonal at `split` columns; the leading part is inverted in the background once its
     // columns are final (after the chain of panel split/NBO - 1), together with the first top-level product
     // (below n = 5120 the cross-stream split costs more than the overlap returns: 3.66 vs 3.79 ms at n = 4096)
-    const int split = (Minv && la && ctx->bg && n / NBO >= 4 && n >= 5120) ? ((n + NBO - 1) / NBO / 2) * NBO : 0;
+    const int split = (Minv && la && ctx->bg && n / NBO >= 4 && n >= 5120 && nexp == 1) ? ((n + NBO - 1) / NBO / 2) * NBO : 0;
     const long NBW = std::min<long>(n, NBO_MAX);
     T* flagw = invD + (long)n * NB;       // flag words of the coupled chain
     T* Wt = flagw + pg_flag_elems(n);     // (PG_PANEL_MODE=1 only) inverse of the current panel's triangular factor, leading dimension = panel width
@@ -592,7 +607,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     return rc;
             }
         }
-        const int mode = (oend < n && pg_panel_mode_env() == 1) ? ctx->panel_mode : 0;
+        const int mode = (oend < n && pg_panel_mode_env() == 1 && nexp == 1) ? ctx->panel_mode : 0;
         const bool v2 = mode == 1;
         const int tri_end = v2 ? oend : n;     // last row the panel stream's 128-column steps touch
         for (int k0 = o0; k0 < oend && !cp; k0 += NB) {
@@ -603,18 +618,20 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 p.M = tri_end - k0; p.N = NB; p.K = k0 - o0;
                 p.A = A + (long)k0 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = Akk; p.ldc = lda;
                 p.alpha = (T)-1; p.beta = (T)1;
+                batched(p, eA, eA, eA);
                 // fewer than two 64-row workgroups per CU: half the row tile keeps two waves on every SIMD (gemm.h); in the
                 // chain-bound tail the launch's latency is what counts: 32 x 32 tiles with a 64-deep K tile
                 static const int u32rows = getenv("PG_U32_ROWS") ? atoi(getenv("PG_U32_ROWS")) : 8192;
                 const int uv = (p.M <= u32rows && p.K % 64 == 0) ? GEMM_NT_32x32 : (p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64);
                 if ((rc = pg_gemm<T>(ctx, ps, uv, p))) return rc;
             }
-            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0))) return rc;
+            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0, 0, nexp, eA, eI))) return rc;
             const int m = tri_end - k0 - NB;
             if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
                 GemmP<T> p = gp0<T>(); p.info = info;
                 p.M = m; p.N = NB; p.K = NB; p.A = Akk + (long)NB * lda; p.lda = lda; p.B = inv; p.ldb = NB;
                 p.C = Akk + (long)NB * lda; p.ldc = lda; p.khi = 2;
+                batched(p, eA, eI, eA);
                 if ((rc = pg_gemm<T>(ctx, ps, m <= 12288 ? GEMM_NT_32x128 : GEMM_NT_64x128, p))) return rc;
             }
         }
@@ -649,8 +666,9 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
             p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1;
+            batched(p, eA, eA, eA);
             // few 128x128 tiles with a 1024-deep K loop leave most CUs idle: use 64x64 tiles then (4x the workgroups)
-            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            const long tiles = (long)(p.M / 128) * (p.N / 128) * nexp;
             if (la && o > 0) {   // these columns were last written by Sb(o-1)
                 if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
                 PG_CHECK(hipStreamWaitEvent(cs, ev, 0));
@@ -669,7 +687,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
             p.C = A + (long)o2 * lda + o2; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
-            const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2;
+            batched(p, eA, eA, eA);
+            const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2 * nexp;
             // (threshold swept 512 / 1024 / 2048: 2048 is 2 % faster at n = 8192 and neutral at 16384)
             // (re-swept with the eight-wave blocks, 2048 / 1024 / 512 / 256: 2048 stays best at 8192, neutral at 16384)
             if ((rc = pg_gemm<T>(ctx, us, tiles < 2048 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
@@ -700,7 +719,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
         }
     }
     if (Minv) {
-        if (!split) return pg_trtri_t<T>(ctx, st, n, A, lda, invD, Minv, ldm);
+        if (!split) return pg_trtri_t<T>(ctx, st, n, A, lda, invD, Minv, ldm, 0, eb);
         // trailing part of the diagonal, then the second top-level product
         const long off = split;
         if ((rc = pg_trtri_t<T>(ctx, st, n - split, A + off * lda + off, lda, invD + (off / NB) * NB * NB, Minv + off * ldm + off, ldm)))
@@ -779,6 +798,18 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
         hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(n / 256, n / 256), dim3(256), 0, st, M, ldm, x, work, (long)n, 1);
         hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256), dim3(256), 0, st, work, (long)n, n / 256, n, y, 1, 0.0, 1.0, 0);
     }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// alpha_e = Minv_e^T (Minv_e y_e) for nexp experts in three launches (u_e, work_e: scratch of n and (n/256) n elements per expert)
+template <typename T>
+int pg_alpha_batched_t(hipStream_t st, int n, const T* M, long ldm, long eM, const T* y, long ey, T* u, long eu, T* alpha, long ea, T* work,
+                       long ew, int nexp) {
+    if (n <= 0 || n % PG_PAD || nexp < 1) { pg_set_error("pg_alpha_batched: n=%d (multiple of %d), nexp=%d", n, PG_PAD, nexp); return -2; }
+    hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((n + 15) / 16, 1, nexp), dim3(256), 0, st, M, ldm, n, y, u, eM, ey, eu);
+    hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(n / 256, n / 256, nexp), dim3(256), 0, st, M, ldm, (const T*)u, work, (long)n, 1, eM, eu, ew);
+    hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256, 1, nexp), dim3(256), 0, st, (const T*)work, (long)n, n / 256, n, alpha, 1, 0.0, 1.0, 0, ew, ea);
     LAUNCH_CHECK();
     return 0;
 }
@@ -946,12 +977,13 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 }
 
 #define INST(T)                                                                                                        \
-    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*);            \
+    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*, const ExpBatch*); \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
-    template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int);                         \
+    template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int, const ExpBatch*);       \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
     template int pg_logdet_t<T>(hipStream_t, int, const T*, long, double*);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
+    template int pg_alpha_batched_t<T>(hipStream_t, int, const T*, long, long, const T*, long, T*, long, T*, long, T*, long, int); \
     template int pg_alpha_nlml_async_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, T*, T*, double*); \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \

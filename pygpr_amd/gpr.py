@@ -13,6 +13,7 @@ Differences a caller can observe:
   * assigning `model.x` / `model.y` marks the model dirty (the reference keeps a stale factor there)
   * `krn`, `krnchd`, `wt` are read-only views materialised on access
 """
+import os
 from typing import Sequence
 
 import torch
@@ -22,6 +23,12 @@ from ._ops import JITTER, get_ops, pad_to
 from .covar import Covar, layout, spec_of
 
 _CHUNK = 8192  # test points per device batch
+# Experts of a batched model are factorised in ONE batched call (every launch covers all experts: pg_build_potrf_trtri_batched)
+# up to this padded size; above it the per-step launches no longer matter and each expert takes the single-model schedule with
+# its flag-coupled chain, one after the other.  PG_BATCH_MAX_N overrides (0: never batch).
+_BATCH_MAX_N = int(os.environ.get("PG_BATCH_MAX_N", "12288"))
+_BATCH_EAGER_N = 4096   # batched experts up to this size form L^-1 with the factor even when nobody asked for variances: the
+                        # batched inverse + three batched mat-vec launches are cheaper than one substitution sweep per expert
 
 
 class ChainTimeout(torch.linalg.LinAlgError):
@@ -133,6 +140,8 @@ class Exact_GP(GPR):
         self._experts = None
         self._data = None
         self._data_key = None
+        self._bat = None
+        self._x_all = self._y_all = None
         self.need_upd: bool = True
         # eager_inverse: form L^-1 inside update() (fused with the Cholesky) and take alpha = L^-T (L^-1 y) from two
         # triangular mat-vecs.  Worth it whenever predictive variances follow (grBCM experts); wasted work otherwise.
@@ -167,16 +176,19 @@ class Exact_GP(GPR):
             nbd = max(xb.shape[0], yb.shape[0])
             if xb.shape[0] not in (1, nbd) or yb.shape[0] not in (1, nbd):
                 raise RuntimeError("batch dimensions of x and y do not broadcast")
-            xs = [ops.to_device(xb[b], self.dtype) for b in range(xb.shape[0])]
+            x_all = ops.to_device(xb, self.dtype)                       # [nbx, n, d]: ONE upload; experts take views
+            n_pad = pad_to(xb.shape[1])
+            y_all = ops.zeros(nbd, n_pad, dtype=self.dtype)
+            y_all[:, : xb.shape[1]] = ops.to_device(yb, self.dtype).expand(nbd, -1) if yb.shape[0] != nbd else ops.to_device(yb, self.dtype)
             data = []
             for b in range(nbd):
                 dt = _Data()
                 dt.n = xb.shape[1]
-                dt.n_pad = pad_to(dt.n)
-                dt.x = xs[b % len(xs)]
-                dt.y = ops.zeros(dt.n_pad, dtype=self.dtype)
-                dt.y[: dt.n] = ops.to_device(yb[b % yb.shape[0]], self.dtype)
+                dt.n_pad = n_pad
+                dt.x = x_all[b % x_all.shape[0]]
+                dt.y = y_all[b]
                 data.append(dt)
+            self._x_all, self._y_all = x_all, y_all
             self._data, self._data_key = data, key
             self._experts = None
         return self._data
@@ -190,8 +202,43 @@ class Exact_GP(GPR):
             raise RuntimeError("batch dimensions of params and x do not broadcast")
         if self._experts is None or len(self._experts) != nb:
             self._experts = [_Expert(data[b % len(data)]) for b in range(nb)]
+            self._bat = None
             self.need_upd = True
         return self._experts
+
+    def _batch(self):
+        """Stacked buffers of a batched model whose experts are factorised together: chol / invd / alpha / info (and minv, work
+        when the inverse is eager) as [nexp, ...] tensors, the experts holding views.  None when the model is not batched that way
+        (one expert, a Compose longer than one pg_covspec, or experts above _BATCH_MAX_N)."""
+        experts = self._experts
+        n_pad = experts[0].n_pad
+        spec, _ = spec_of(self.cov, self._x.shape[-1])
+        if len(experts) < 2 or n_pad > _BATCH_MAX_N or isinstance(spec, (list, tuple)) and len(spec) != 1:
+            return None
+        if self._bat is None:
+            ops = get_ops()
+            nb = len(experts)
+            bat = {
+                "chol": ops.empty(nb, n_pad, n_pad, dtype=self.dtype),
+                "invd": ops.empty(nb, ops.potrf_worksize(n_pad, self.dtype), dtype=self.dtype),
+                "alpha": ops.empty(nb, n_pad, dtype=self.dtype),
+                "info": torch.zeros(nb, dtype=torch.int32, device=ops.device),
+                "hp": ops.empty(nb, self.params.shape[-1], dtype=torch.float64),
+                "minv": None, "work": None,
+            }
+            for b, e in enumerate(experts):
+                e.chol, e.invd, e.alpha, e.info, e.hp = bat["chol"][b], bat["invd"][b], bat["alpha"][b], bat["info"][b: b + 1], bat["hp"][b]
+            self._bat = bat
+        self._bat["eager"] = self.eager_inverse or n_pad <= _BATCH_EAGER_N
+        if self._bat["eager"] and self._bat["minv"] is None:
+            ops = get_ops()
+            nb = len(experts)
+            self._bat["minv"] = ops.empty(nb, n_pad, n_pad, dtype=self.dtype)
+            self._bat["u"] = ops.empty(nb, n_pad, dtype=self.dtype)
+            self._bat["work"] = ops.empty(nb, (n_pad // 256) * n_pad, dtype=self.dtype)
+            for b, e in enumerate(experts):
+                e.minv = self._bat["minv"][b]
+        return self._bat
 
     def _hp_rows(self):
         nhp = self.params.shape[-1]
@@ -206,7 +253,22 @@ class Exact_GP(GPR):
             spec, nhp = spec_of(self.cov, self._x.shape[-1])
             assert hp_rows.shape[-1] == nhp
 
-            def enqueue():
+            bat = self._batch()
+
+            def enqueue_batched():
+                # all experts in one call: every launch of the blocked factorisation (and of L^-1) covers the whole batch
+                bat["hp"].copy_(hp_rows.expand(len(experts), -1) if hp_rows.shape[0] == 1 else hp_rows)
+                x_stride = self._x_all.stride(0) if self._x_all.shape[0] > 1 else 0
+                ops.build_factor_batched(spec, bat["hp"], self._x_all, x_stride, bat["chol"], bat["invd"], bat["info"],
+                                         bat["minv"] if bat["eager"] else None)
+                if bat["eager"]:
+                    ops.alpha_batched(bat["minv"], self._y_all, bat["u"], bat["alpha"], bat["work"])
+                for e in experts:
+                    e.minv_valid = bat["eager"]
+                    if not bat["eager"]:
+                        ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
+
+            def enqueue_serial():
                 for b, e in enumerate(experts):
                     e.hp = ops.to_device(hp_rows[b % hp_rows.shape[0]], torch.float64)
                     if e.chol is None:
@@ -227,6 +289,8 @@ class Exact_GP(GPR):
                         e.minv_valid = False
                         ops.build_factor(spec, e.hp, e.x, e.chol, e.invd, e.info)
                         ops.potrs_vec(e.chol, e.invd, e.y, e.alpha)
+
+            enqueue = enqueue_batched if bat is not None else enqueue_serial
 
             # one sync point after everything is enqueued; a timed-out coupled chain repeats the lot on the classic chain
             for info in _checked(enqueue, lambda: torch.cat([e.info for e in experts]).tolist()):

@@ -98,20 +98,24 @@ class MLE(Loss):
         if len(experts) not in (1, rows.shape[0]) and rows.shape[0] != 1:
             raise RuntimeError("batch dimensions of params and x do not broadcast")
         nb = max(len(experts), rows.shape[0])
-        losses = np.empty(nb)
-        grads = np.empty((nb, nhp))
         self._factor_key = None             # whatever the buffers held is overwritten below
-        for b in range(nb):
-            e = experts[b % len(experts)]
-            buf = self._buffers(e.n_pad, model.dtype, nhp, e.n)
-            hp = ops.to_device(torch.from_numpy(np.array(rows[b % rows.shape[0]], dtype=np.float64)), torch.float64)
-            a, out = buf["a"], buf["out"]
-            if want_grad and buf["m"] is None:
-                buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
-            m = buf["m"]
-            res = [None]
+        # Every expert's evaluation is enqueued before the ONE synchronisation that reads all results: the experts share the n x n
+        # work buffers (stream order makes that safe), each has its own result / status slot.  (Round 2 synchronised per expert.)
+        hp_all = ops.to_device(torch.from_numpy(np.array(np.broadcast_to(rows, (nb, nhp)), dtype=np.float64)), torch.float64)
+        outs = ops.zeros(nb, 1 + nhp, dtype=torch.float64)
+        vals = ops.zeros(nb, 2, dtype=torch.float64)
+        infos = torch.zeros(nb, dtype=torch.int32, device=ops.device)
+        res = [None]
 
-            def enqueue():
+        def enqueue():
+            for b in range(nb):
+                e = experts[b % len(experts)]
+                buf = self._buffers(e.n_pad, model.dtype, nhp, e.n)
+                hp, out, info, val = hp_all[b], outs[b], infos[b: b + 1], vals[b]
+                a = buf["a"]
+                if want_grad and buf["m"] is None:
+                    buf["m"] = ops.empty(e.n_pad, e.n_pad, dtype=model.dtype)
+                m = buf["m"]
                 if reuse_factor and nb == 1:
                     # `a` still holds the factor and buf["alpha"] the weights of the loss-only evaluation at these parameters
                     ops.trtri(a, buf["invd"], m)
@@ -119,26 +123,25 @@ class MLE(Loss):
                     ops.lauum(m, a)
                     ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])
                 elif want_grad:
-                    ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"], m)   # covariance build + Cholesky + L^-1 in one call
+                    ops.build_factor(spec, hp, e.x, a, buf["invd"], info, m)   # covariance build + Cholesky + L^-1 in one call
                     # alpha = L^-T (L^-1 y) and the NLML value on the library's side stream, beside K^-1 = L^-T L^-1 (lower, over a)
-                    ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, buf["val"])
+                    ops.alpha_nlml_async(a, m, e.y, buf["u"], buf["alpha"], buf["vwork"], e.n, val)
                     ops.lauum(m, a)
                     ops.nlml_grad(spec, hp, e.x, e.n, a, buf["alpha"], out[1:], buf["gwork"])   # waits for the side stream
-                    out[0:1].copy_(buf["val"][0:1])
+                    out[0:1].copy_(val[0:1])
                 else:
-                    ops.build_factor(spec, hp, e.x, a, buf["invd"], buf["info"])
+                    ops.build_factor(spec, hp, e.x, a, buf["invd"], info)
                     ops.potrs_vec(a, buf["invd"], e.y, buf["alpha"])
                     ops.nlml_value(a, e.y, buf["alpha"], e.n, out)
-                res[0] = out.cpu().numpy()                              # the one sync + transfer
+            res[0] = outs.cpu().numpy()                                     # the one sync + transfer
 
-            # (a timed-out coupled chain -- info = -1 -- repeats the evaluation on the classic chain; the re-used factor of a
-            # loss-only evaluation was checked when it was made, so that branch cannot time out)
-            info = _checked(enqueue, lambda: [buf["info"].item()])[0]
-            res = res[0]
+        # (a timed-out coupled chain -- info = -1 -- repeats the evaluation on the classic chain; the re-used factor of a
+        # loss-only evaluation was checked when it was made, so that branch cannot time out)
+        for info in _checked(enqueue, lambda: infos.tolist()):
             if info:
                 raise _lin_alg_error(info)
-            losses[b] = res[0]
-            grads[b] = res[1:]
+        losses = res[0][:, 0].copy()
+        grads = res[0][:, 1:].copy()
         if not want_grad and nb == 1 and key is not None:
             self._factor_key = key
         batched = nb > 1      # a batch of one is squeezed away (llhd.squeeze_(0), loss.py:51,85,111)

@@ -112,6 +112,19 @@ class OracleOps:
             idx = np.tril_indices(m.shape[0])
             _np(a)[idx] = low[idx]
 
+    def alpha_batched(self, minv_all, y_all, u_all, alpha_all, work_all):
+        for e in range(minv_all.shape[0]):
+            self.trmv(minv_all[e], y_all[e % y_all.shape[0]], u_all[e], 0)
+            self.trmv(minv_all[e], u_all[e], alpha_all[e], 1, work_all[e])
+
+    def potrf_worksize(self, n_pad, dtype):
+        return n_pad * NB
+
+    def build_factor_batched(self, spec, hp_all, x_all, x_stride, a_all, invd_all, info_all, minv_all=None, jitter=1e-7):
+        for e in range(a_all.shape[0]):
+            self.build_factor(spec, hp_all[e], x_all[e if x_stride else 0], a_all[e], invd_all[e], info_all[e: e + 1],
+                              minv_all[e] if minv_all is not None else None, jitter)
+
     def build_factor(self, spec, hp, x, a, invd, info, minv=None, jitter=1e-7):
         self.kernel_build(spec, hp, x, None, a, lower_only=True, jitter=jitter)
         return self.potrf_trtri(a, invd, info, minv) if minv is not None else self.potrf(a, invd, info)

@@ -853,3 +853,63 @@ def test_build_potrf_trtri_checked_falls_back_inside_the_call(ops, forced_timeou
     t0 = time.perf_counter()
     assert ops.build_factor_checked(spec, hpd, xd, a, invd, info, minv, jitter=1e-7) == 0
     assert time.perf_counter() - t0 < 0.25 and ops.last_coupled_panels() == 0
+
+
+# ---- batched experts: one call, every launch covers all of them (PyGPR/gpr.py:65-74 factorises a batch in one tc.cholesky) ------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nexp,n,with_inv", [(8, 4096, True), (3, 1000, False), (10, 100, True)])
+def test_batched_factorisation(ops, nexp, n, with_inv):
+    """pg_build_potrf_trtri_batched against LAPACK per expert (factor 1e-11, inverse 1e-9), and bit for bit against the
+    single-expert call on the classic chain (the batch only widens the grids); expert 1 gets different hyper-parameters, and a
+    NaN in ONE expert's points fails that expert alone (info[e] > 0, the others' factors untouched)."""
+    from pygpr_amd._ops import pad_to
+
+    d = 4
+    covs = [orc.SE, orc.WN]
+    rng = np.random.default_rng(1000 + n)
+    x = rng.random((nexp, n, d))
+    hp = np.tile(np.array([1.0, 0.9, 1.1, 0.8, 1.2, 0.1]), (nexp, 1))
+    hp[1] = [1.3, 0.5, 0.7, 1.4, 0.6, 0.2]
+    npad = pad_to(n)
+    spec = _spec(covs, d)
+    hpd, xd = dev(hp), dev(x)
+    a = ops.empty(nexp, npad, npad)
+    invd = ops.empty(nexp, ops.potrf_worksize(npad, torch.float64))
+    info = torch.ones(nexp, dtype=torch.int32, device="cuda")
+    minv = ops.zeros(nexp, npad, npad) if with_inv else None
+    ops.build_factor_batched(spec, hpd, xd, xd.stride(0), a, invd, info, minv, jitter=1e-7)
+    assert info.tolist() == [0] * nexp and ops.last_coupled_panels() == 0
+    la, lm = host(a), (host(minv) if with_inv else None)
+    for e in sorted({0, 1, nexp - 1}):
+        k = orc.kernel(covs, hp[e], x[e], form="direct") + 1e-7 * np.eye(n)
+        chol = np.linalg.cholesky(k)
+        np.testing.assert_allclose(np.tril(la[e])[:n, :n], chol, atol=1e-11)
+        if with_inv:
+            np.testing.assert_allclose(np.tril(lm[e])[:n, :n], np.linalg.inv(chol), atol=1e-9)
+    # the same expert alone, classic chain: identical bits
+    ops.set_coupled_chain(0)
+    try:
+        for e in (1, nexp - 1):
+            a1 = ops.empty(npad, npad)
+            i1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            m1 = ops.zeros(npad, npad) if with_inv else None
+            ops.build_factor(spec, hpd[e], xd[e], a1, ops.potrf_workspace(npad, torch.float64), i1, m1, jitter=1e-7)
+            assert int(i1.item()) == 0
+            np.testing.assert_array_equal(np.tril(host(a1)), np.tril(la[e]))
+            if with_inv:
+                np.testing.assert_array_equal(np.tril(host(m1)), np.tril(lm[e]))
+    finally:
+        ops.set_coupled_chain(1)
+    # one bad expert fails alone
+    xb = x.copy()
+    xb[2 % nexp, 5, 0] = np.nan
+    a2 = ops.empty(nexp, npad, npad)
+    ops.build_factor_batched(spec, hpd, dev(xb), xd.stride(0), a2, invd, info, None, jitter=1e-7)
+    got = info.tolist()
+    assert got[2 % nexp] > 0 and all(v == 0 for i, v in enumerate(got) if i != 2 % nexp)
+    np.testing.assert_array_equal(np.tril(host(a2[0])), np.tril(la[0]))
+    # shared points (x_stride = 0): experts differ by their hyper-parameters only
+    ops.build_factor_batched(spec, hpd, xd[:1].contiguous(), 0, a2, invd, info, None, jitter=1e-7)
+    assert info.tolist() == [0] * nexp
+    k = orc.kernel(covs, hp[1], x[0], form="direct") + 1e-7 * np.eye(n)
+    np.testing.assert_allclose(np.tril(host(a2[1]))[:n, :n], np.linalg.cholesky(k), atol=1e-11)

@@ -706,3 +706,32 @@ def test_default_hp_gradient_error_is_stated(golden, capsys):
     with capsys.disabled():
         for r in rows:
             print("\n[default-hp parity] case %s n=%d cond(K)=%.2e  NLML rel err %.2e  grad err/|g|inf %.2e  (rule 50 eps cond = %.1e)" % r)
+
+
+@pytest.mark.gpu
+def test_reference_test_sizes_batched(golden):
+    """The reference's own test sizes (PyGPR/tests/test_gpr.py:59-100: nc = 10 experts of n = 100 points; tests/test_grbcm.py:18-37:
+    nc = 5, ng = 100, nls = 50) against what the imported reference returned (round3.npz).  The experts of such a model are
+    factorised in one batched call (every launch covers all ten)."""
+    from pygpr_amd._ops import get_ops
+
+    r = golden("round3")
+    gp = pg.Exact_GP(T(r["sm_x"]), T(r["sm_y"]), se_wn())
+    gp.set_params(T(r["sm_hp"]))
+    mu, var = gp.predict(T(r["sm_xp"]), var="diag")
+    assert gp._bat is not None and get_ops().last_coupled_panels() == 0          # the batched path ran
+    np.testing.assert_allclose(N(mu), r["sm_mu"], atol=1e-10)
+    np.testing.assert_allclose(N(var), r["sm_var"], atol=1e-11)
+    np.testing.assert_allclose(N(gp.wt), r["sm_wt"], rtol=1e-9, atol=1e-9)
+    loss, grad = pg.MLE(gp).loss_and_grad(r["sm_hp"].copy())
+    np.testing.assert_allclose(loss, r["sm_loss"], rtol=1e-10)
+    np.testing.assert_allclose(grad, r["sm_grad"], rtol=1e-8, atol=1e-8 * np.abs(r["sm_grad"]).max())
+    nc = r["sg_xl"].shape[0]
+    g = pg.GRBCM(T(r["sg_xl"]), T(r["sg_yl"]), T(r["sg_xg"]), T(r["sg_yg"]), se_wn())
+    g.set_params(T(r["sg_hp"]))
+    mu, var = g.predict(T(r["sg_xl"][2]), var="diag")
+    assert g.gpl._bat is not None and len(g.gpl._experts) == nc
+    np.testing.assert_allclose(N(mu), r["sg_mu"], atol=1e-9)
+    np.testing.assert_allclose(N(var), r["sg_var"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(N(g.beta), r["sg_beta"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mu.numpy(), np.sin(r["sg_xl"][2].sum(-1)), atol=1e-2)      # test_grbcm.py:36 (its data has no noise)
