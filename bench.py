@@ -437,13 +437,13 @@ def main():
                 best = min(best, e0.elapsed_time(e1))
             return best
 
-        t_build = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, jitter=1e-7), 5)
+        t_build = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, jitter=1e-7), 10)
         bytes_build = 8.0 * n * n + 8.0 * n * d
         out["roofline_kernel_build"] = {
             "bound": "hbm", "achieved": bytes_build / t_build / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_build / t_build / 1e6 / HBM_PEAK_GBS, "ms": t_build, "algorithmic_bytes": bytes_build,
         }
-        t_lower = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)
+        t_lower = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 10)
         bytes_lower = 4.0 * n * (n + 64) + 8.0 * n * d
         out["roofline_kernel_build"]["lower_only"] = {"ms": t_lower, "algorithmic_bytes": bytes_lower,
                                                       "achieved": bytes_lower / t_lower / 1e6,

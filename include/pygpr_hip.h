@@ -127,6 +127,16 @@ long pg_potrs_vec_worksize(int dtype, int n);
 int pg_potrs_vec(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, const void* y, void* x,
                  void* work, void* stream);
 
+/* Matrix right-hand sides: tc.cholesky_solve(B, L) of gpr.py:100,112 / loss.py:116 (pg_potrs: X = K^-1 B) and its triangular half
+ * (pg_trsm_lower: X = L^-1 B).  B [n x nrhs] and X [n x nrhs] row-major, nrhs a multiple of 128 (pad with zero columns), X != B.
+ * Both run as products of the MFMA GEMM core against L^-1: pass Minv (from pg_trtri / pg_potrf_trtri) or NULL, in which case
+ * pg_trtri forms it in `work` first.  work: pg_potrs_worksize(dtype, n, nrhs, Minv != NULL) elements. */
+long pg_potrs_worksize(int dtype, int n, int nrhs, int have_minv);
+int pg_potrs(pg_handle h, int dtype, int n, int nrhs, const void* L, long ldl, const void* inv_diag, const void* Minv, long ldm, const void* B,
+             long ldb, void* X, long ldx, void* work, void* stream);
+int pg_trsm_lower(pg_handle h, int dtype, int n, int nrhs, const void* L, long ldl, const void* inv_diag, const void* Minv, long ldm,
+                  const void* B, long ldb, void* X, long ldx, void* work, void* stream);
+
 /* Minv = L^-1 (lower; its strictly upper blocks are scratch).  First half of cholesky_solve against a
  * matrix right-hand side (gpr.py:100,112; loss.py:116). */
 int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void* inv_diag, void* Minv, long ldm,

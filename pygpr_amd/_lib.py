@@ -72,6 +72,9 @@ _SIGS = {
     "pg_build_potrf_trtri_batched": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _l, _vp, _l, _l, _i, _i, _d, _vp, _l, _l, _i, _vp, _l, _vp, _vp,
                                           _l, _l, _i, _vp]),
     "pg_alpha_batched": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _vp]),
+    "pg_potrs_worksize": (_l, [_i, _i, _i, _i]),
+    "pg_potrs": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp]),
+    "pg_trsm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp]),
     "pg_set_spin_budget": (_i, [_vp, _l]),
     "pg_chain_timeouts": (_i, [_vp]),
     "pg_last_coupled_panels": (_i, [_vp]),

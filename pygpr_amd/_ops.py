@@ -176,6 +176,18 @@ class HipOps:
         _lib.check(self.lib.pg_potrs_vec(self.h, _code(chol.dtype), chol.shape[0], _p(chol), chol.stride(0), _p(invd),
                                          _p(y), _p(x), _p(work), self._st()), "pg_potrs_vec")
 
+    def potrs(self, chol, invd, b, minv=None, triangular_only=False):
+        """x = K^-1 b (or L^-1 b) for a matrix right-hand side b [n_pad, nrhs_pad] (nrhs_pad a multiple of 128): pg_potrs / pg_trsm_lower."""
+        n, nrhs = b.shape
+        x = self.empty(n, nrhs, dtype=b.dtype)
+        work = self.empty(self.lib.pg_potrs_worksize(_code(b.dtype), n, nrhs, int(minv is not None)), dtype=b.dtype)
+        self._chk(chol, invd, b, minv, x, work)
+        fn = self.lib.pg_trsm_lower if triangular_only else self.lib.pg_potrs
+        _lib.check(fn(self.h, _code(b.dtype), n, nrhs, _p(chol), chol.stride(0) if chol is not None else 0, _p(invd), _p(minv),
+                      minv.stride(0) if minv is not None else 0, _p(b), b.stride(0), _p(x), x.stride(0), _p(work), self._st()),
+                   "pg_trsm_lower" if triangular_only else "pg_potrs")
+        return x
+
     def potri(self, chol, invd, kinv, work=None):
         """kinv(lower) = K^-1 from the factor (pg_trtri + pg_lauum in one call)."""
         n = chol.shape[0]

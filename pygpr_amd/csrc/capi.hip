@@ -426,6 +426,32 @@ int pg_trtri(pg_handle h, int dtype, int n, const void* L, long ldl, const void*
              pg_trtri_t<float>(h, ST(stream), n, (const float*)L, ldl, (const float*)inv_diag, (float*)Minv, ldm));
 }
 
+long pg_potrs_worksize(int dtype, int n, int nrhs, int have_minv) {
+    (void)dtype;
+    return (have_minv ? 0L : (long)n * n) + (long)n * nrhs;
+}
+
+static int potrs_any(pg_handle h, int dtype, int n, int nrhs, const void* L, long ldl, const void* inv_diag, const void* Minv, long ldm,
+                     const void* B, long ldb, void* X, long ldx, void* work, int both, void* stream) {
+    JOIN(h, stream);
+    NEED(h && B && X && work && (Minv || (L && inv_diag)), "null pointer");
+    NEED(ldb >= nrhs && ldx >= nrhs && (Minv ? ldm >= n : ldl >= n), "leading dimension too small");
+    NEED(B != X, "out of place: X must not alias B");
+    DISPATCH(dtype,
+             pg_potrs_t<double>(h, ST(stream), n, nrhs, (const double*)L, ldl, (const double*)inv_diag, (const double*)Minv, ldm,
+                                (const double*)B, ldb, (double*)X, ldx, (double*)work, both),
+             pg_potrs_t<float>(h, ST(stream), n, nrhs, (const float*)L, ldl, (const float*)inv_diag, (const float*)Minv, ldm, (const float*)B,
+                               ldb, (float*)X, ldx, (float*)work, both));
+}
+int pg_potrs(pg_handle h, int dtype, int n, int nrhs, const void* L, long ldl, const void* inv_diag, const void* Minv, long ldm, const void* B,
+             long ldb, void* X, long ldx, void* work, void* stream) {
+    return potrs_any(h, dtype, n, nrhs, L, ldl, inv_diag, Minv, ldm, B, ldb, X, ldx, work, 1, stream);
+}
+int pg_trsm_lower(pg_handle h, int dtype, int n, int nrhs, const void* L, long ldl, const void* inv_diag, const void* Minv, long ldm,
+                  const void* B, long ldb, void* X, long ldx, void* work, void* stream) {
+    return potrs_any(h, dtype, n, nrhs, L, ldl, inv_diag, Minv, ldm, B, ldb, X, ldx, work, 0, stream);
+}
+
 int pg_lauum(pg_handle h, int dtype, int n, const void* Minv, long ldm, void* Kinv, long ldk, void* stream) {
     NEED(h && Minv && Kinv, "null pointer");
     NEED(Minv != Kinv, "pg_lauum is out of place");

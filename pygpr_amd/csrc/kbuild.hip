@@ -71,27 +71,39 @@ __device__ __forceinline__ void stage_points(T* dst, const T* __restrict__ X, lo
     }
 }
 
-// Tile (tr, tc) of workgroup `b` of a 1-D grid.  Symmetric builds launch ONLY the tiles on or below the diagonal (round 2
-// launched the full square and let the upper half exit at once): column window [c0, c1) in tiles, T tile rows --
-//   rows c0 .. c1-1 hold tr - c0 + 1 tiles (the triangle), rows c1 .. T-1 hold c1 - c0 (the rectangle below it).
-__device__ __forceinline__ void kb_tile_of(int b, int symmetric, int c0, int c1, int& tr, int& tc) {
-    const int W = c1 - c0;
+// Strip (tile row tr, first tile tcs, ntile tiles) of workgroup `b` of a 1-D grid: a workgroup walks up to S consecutive tiles of
+// one tile row.  Symmetric builds launch ONLY tiles on or below the diagonal (round 2 launched the full square and let the upper
+// half exit at once): column window [c0, c1) in tiles --
+//   tile rows c0 .. c1-1 hold r' + 1 tiles (r' = tr - c0: the triangle) = ceil((r' + 1) / S) strips,
+//   tile rows c1 .. T-1 hold W = c1 - c0 tiles (the rectangle below it) = ceil(W / S) strips.
+__host__ __device__ __forceinline__ long kb_strips_before(int rp, int S) {      // strips in triangle rows 0 .. rp-1
+    const long q = rp / S, rem = rp % S;
+    return (long)S * q * (q + 1) / 2 + rem * (q + 1);
+}
+__device__ __forceinline__ void kb_strip_of(int b, int symmetric, int c0, int c1, int S, int& tr, int& tcs, int& ntile) {
+    const int W = c1 - c0, SW = (W + S - 1) / S;
     if (!symmetric) {
-        tr = b / W;
-        tc = c0 + b % W;
+        tr = b / SW;
+        tcs = c0 + (b % SW) * S;
+        ntile = min(S, c1 - tcs);
         return;
     }
-    const int ntri = W * (W + 1) / 2;
+    const int ntri = (int)kb_strips_before(W, S);
     if (b < ntri) {
-        int r = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-        while (r * (r + 1) / 2 > b) --r;
-        while ((r + 1) * (r + 2) / 2 <= b) ++r;
-        tr = c0 + r;
-        tc = c0 + b - r * (r + 1) / 2;
+        int q = (int)((sqrtf(1.0f + 8.0f * (float)b / (float)S) - 1.0f) * 0.5f);
+        while (q > 0 && (long)S * q * (q + 1) / 2 > b) --q;
+        while ((long)S * (q + 1) * (q + 2) / 2 <= b) ++q;
+        const int within = b - S * q * (q + 1) / 2;         // strips into the block of S rows that hold q + 1 strips each
+        const int rem = within / (q + 1), sidx = within % (q + 1);
+        const int rp = S * q + rem;
+        tr = c0 + rp;
+        tcs = c0 + sidx * S;
+        ntile = min(S, rp + 1 - sidx * S);
     } else {
         const int j = b - ntri;
-        tr = c1 + j / W;
-        tc = c0 + j % W;
+        tr = c1 + j / SW;
+        tcs = c0 + (j % SW) * S;
+        ntile = min(S, c1 - tcs);
     }
 }
 
@@ -119,7 +131,8 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) sq[r][c] = (T)0;
-        for (int k = 0; k < d; ++k) {
+#pragma unroll 2
+        for (int k = 0; k < d; ++k) {      // (two coordinates' LDS reads in flight per trip)
             T a[4], b[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = xr[k * KT + ty * 4 + r];
@@ -148,10 +161,26 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
                     }
             }
         }
+        // the kind is decided ONCE for the sixteen elements: with the dispatch inside the element loop every covariance value sat
+        // behind its own branch and the sixteen exponentials ran one after the other, each a chain of dependent operations
+        const int kind = spec.kind[cp];
+        const T s2 = sg2[cp];
+        if (kind == PG_KIND_RBF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[r][c] += comp_value<T>(spec.kind[cp], sg2[cp], sq[r][c]);
+                for (int c = 0; c < 4; ++c) out[r][c] += s2 * pg_exp(-sq[r][c]);
+        } else if (kind == PG_KIND_SQDIST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[r][c] += sq[r][c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[r][c] += comp_value<T>(PG_KIND_MATERN52, s2, sq[r][c]);
+        }
     }
     const T dg = sg2[PG_MAX_COMP];
     const bool mirror = MIRROR && tc < tr;
@@ -195,28 +224,56 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
     }
 }
 
-template <typename T, bool MIRROR>   // MIRROR: a symmetric build that also writes the transposed tiles above the diagonal
+// MIRROR: a symmetric build that also writes the transposed tiles above the diagonal.  NPF: point coordinates a thread stages per
+// tile (64 d / 256, rounded up to 2, 4 or 16).
+// A workgroup walks a STRIP of up to S tiles of one tile row (round 2: one tile per workgroup): the row's points, the hyper-parameters
+// and the launch are paid once per strip, and the next tile's column points are fetched (global -> registers -> the other LDS
+// buffer) while the current tile is computed.  A tile's time was 7 us of staging latency, synchronisation and drain around 1 us of
+// arithmetic with four workgroups per CU to hide it (rocprof: 2.55 TB/s on the lower-only build); the strip hides it behind work.
+template <typename T, bool MIRROR, int NPF>
 __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                         const T* __restrict__ Xr, long ldr, int nr,
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
                                                         int symmetric, int accumulate, double jitter,
-                                                        T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int sq_grid,
+                                                        T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int S,
                                                         long eX, long ehp, long eK) {
     // batched experts (symmetric builds): blockIdx.y = expert, each with its own points, hyper-parameters and matrix
     Xr += blockIdx.y * eX; Xc += blockIdx.y * eX; hp += blockIdx.y * ehp; K += blockIdx.y * eK;
-    int tr, tc;
-    kb_tile_of(blockIdx.x, symmetric && !sq_grid, ctile0, ctile1, tr, tc);
-    if (sq_grid && symmetric && tc > tr) return;    // PG_KB_GRID2D=1 (experiment): round 2's full-square grid
+    int tr, tcs, ntile;
+    kb_strip_of(blockIdx.x, symmetric, ctile0, ctile1, S, tr, tcs, ntile);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* xr = reinterpret_cast<T*>(smem_raw);
-    T* xc = xr + KT * d;
-    T* l2 = xc + KT * d;            // [ncomp][d] squared inverse length scales
+    T* xc = xr + KT * d;            // two buffers [d][64]
+    T* l2 = xc + 2 * KT * d;        // [ncomp][d] squared inverse length scales
     T* sg2 = l2 + PG_MAX_COMP * d;  // [PG_MAX_COMP] sigma^2, then the diagonal term
     T* tt = sg2 + PG_MAX_COMP + 2;  // MIRROR: [64][TLD] transposed tile
     const int tid = threadIdx.x;
     const double* scale = presc ? hp + spec.off[0] + 1 : nullptr;
+    // this thread's share of a point tile: elements idx = tid + 256 u < 64 d  ->  point idx / d, coordinate idx % d
+    int pp[NPF], kk[NPF];
+    double sc[NPF];
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int idx = tid + 256 * u;
+        pp[u] = idx < KT * d ? idx / d : -1;
+        kk[u] = idx < KT * d ? idx % d : 0;
+        sc[u] = (scale && pp[u] >= 0) ? scale[kk[u]] : 1.0;
+    }
+    T pf[NPF];
+    auto load_cols = [&](int tc) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int gp = tc * KT + pp[u];
+            pf[u] = (pp[u] >= 0 && gp < nc) ? (T)((double)Xc[(long)gp * ldc + kk[u]] * sc[u]) : (T)0;
+        }
+    };
+    auto store_cols = [&](T* dst) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            if (pp[u] >= 0) dst[kk[u] * KT + pp[u]] = pf[u];
+    };
+    load_cols(tcs);
     stage_points(xr, Xr, ldr, nr, tr * KT, d, tid, scale);
-    stage_points(xc, Xc, ldc, nc, tc * KT, d, tid, scale);
     for (int idx = tid; idx < spec.ncomp * d; idx += 256) {
         const int c = idx / d, k = idx % d;
         const double l = hp[spec.off[c] + 1 + k];
@@ -231,16 +288,32 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
         for (int i = 0; i < spec.nnoise; ++i) { const double s = hp[spec.noise_off[i]]; dg += s * s; }
         sg2[PG_MAX_COMP] = (T)dg;
     }
+    store_cols(xc);
     __syncthreads();
-    // workgroup-uniform: a tile strictly below the diagonal (or any tile of a cross build) that lies inside the real points
-    const bool interior = !accumulate && (!symmetric || tc < tr) && (tr + 1) * KT <= nr && (tc + 1) * KT <= nc;
-#define KB_ARGS spec, xr, xc, l2, sg2, tt, d, tr, tc, nr, nc, symmetric, accumulate, K, ldk, tid
+    // workgroup-uniform: every tile of the strip lies strictly below the diagonal (or the build is a cross build) and inside the
+    // real points -- the strip then runs the body without per-element fix-ups.  ONE body per workgroup: with both bodies inlined
+    // in the tile loop the kernel needed 160 VGPRs (three workgroups per CU instead of four).
+    const int tcl = tcs + ntile - 1;
+    const bool interior = !accumulate && (!symmetric || tcl < tr) && (tr + 1) * KT <= nr && (tcl + 1) * KT <= nc;
+    auto walk = [&](auto body) {
+        for (int t = 0; t < ntile; ++t) {
+            const int tc = tcs + t;
+            const T* cur = xc + (t & 1) * KT * d;
+            if (t + 1 < ntile) load_cols(tc + 1);           // in flight while this tile is computed
+            body(cur, tc);
+            if (t + 1 < ntile) {
+                store_cols(xc + ((t + 1) & 1) * KT * d);
+                __syncthreads();   // publishes the next tile's points; also orders this tile's reads of `tt` before the next one's writes
+            }
+        }
+    };
+#define KB_ARGS(cur, tc) spec, xr, cur, l2, sg2, tt, d, tr, tc, nr, nc, symmetric, accumulate, K, ldk, tid
     if (presc) {
-        if (interior) kb_body<T, true, false, MIRROR>(KB_ARGS);
-        else kb_body<T, true, true, MIRROR>(KB_ARGS);
+        if (interior) walk([&](const T* cur, int tc) { kb_body<T, true, false, MIRROR>(KB_ARGS(cur, tc)); });
+        else walk([&](const T* cur, int tc) { kb_body<T, true, true, MIRROR>(KB_ARGS(cur, tc)); });
     } else {
-        if (interior) kb_body<T, false, false, MIRROR>(KB_ARGS);
-        else kb_body<T, false, true, MIRROR>(KB_ARGS);
+        if (interior) walk([&](const T* cur, int tc) { kb_body<T, false, false, MIRROR>(KB_ARGS(cur, tc)); });
+        else walk([&](const T* cur, int tc) { kb_body<T, false, true, MIRROR>(KB_ARGS(cur, tc)); });
     }
 #undef KB_ARGS
 }
@@ -255,14 +328,14 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         return -2;
     }
     const bool mirror = symmetric && !lower_only;
-    const size_t lds = (size_t)(2 * KT * d + PG_MAX_COMP * d + PG_MAX_COMP + 2 + (mirror ? KT * TLD : 0)) * sizeof(T);
+    const size_t lds = (size_t)(3 * KT * d + PG_MAX_COMP * d + PG_MAX_COMP + 2 + (mirror ? KT * TLD : 0)) * sizeof(T);
     static bool attr_done = false;
-    if (!attr_done) {   // the mirrored fp64 build passes the 64 KB a kernel gets without opting in from d = 31 (101 KB at d = 64)
-        const size_t lds_max = (size_t)(2 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD) * sizeof(T);
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_kbuild_kernel<T, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    if (!attr_done) {   // large d passes the 64 KB a kernel gets without opting in (134 KB for the mirrored fp64 build at d = 64)
+        const size_t lds_max = (size_t)(3 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD) * sizeof(T);
+        const void* fns[6] = {reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 2>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 4>),
+                              reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 16>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 2>),
+                              reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 4>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 16>)};
+        for (const void* f : fns) PG_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         attr_done = true;
     }
     // columns [col0, col1) only (col1 <= 0: all): a lower-only symmetric build in two column windows lets the factorisation
@@ -277,20 +350,24 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         return -2;
     }
     const int c0 = col0 / KT, c1 = col1 / KT, W = c1 - c0, TR = rows_pad / KT;
+    // strips of up to S tiles of one tile row per workgroup (PG_KB_STRIP; 1 = one tile per workgroup, round 2's granularity)
+    static const int strip_env = getenv("PG_KB_STRIP") ? atoi(getenv("PG_KB_STRIP")) : 8;
+    const int S = std::max(1, std::min(strip_env, 64));
+    const int SW = (W + S - 1) / S;
     // symmetric: the triangle of the window's own tile rows plus the rectangle below it; cross build: every tile of the window
-    static const int sq_grid = getenv("PG_KB_GRID2D") ? atoi(getenv("PG_KB_GRID2D")) : 0;
-    const long tiles = (symmetric && !sq_grid) ? (long)W * (W + 1) / 2 + (long)(TR - c1) * W : (long)TR * W;
-    if (tiles <= 0) return 0;
+    const long strips = symmetric ? kb_strips_before(W, S) + (long)(TR - c1) * SW : (long)TR * SW;
+    if (strips <= 0) return 0;
     // one stationary component (the common Compose([SE, WN])): its inverse length scales go into the staged coordinates.  In fp64
     // (x l) - (x' l) rounds differently from l^2 (x - x')^2 in the last bit; PG_KB_PRESC=0 keeps the unscaled form
     static const int presc_env = getenv("PG_KB_PRESC") ? atoi(getenv("PG_KB_PRESC")) : 1;
     const int presc = (presc_env && spec.ncomp == 1) ? 1 : 0;
-    if (mirror)
-        hipLaunchKernelGGL((pg_kbuild_kernel<T, true>), dim3((unsigned)tiles, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid, eX, ehp, eK);
-    else
-        hipLaunchKernelGGL((pg_kbuild_kernel<T, false>), dim3((unsigned)tiles, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, ldc, nc, d,
-                           symmetric, accumulate, jitter, K, ldk, c0, c1, presc, sq_grid, eX, ehp, eK);
+    const int npf = d <= 8 ? 2 : (d <= 16 ? 4 : 16);
+#define KB_LAUNCH(M, P)                                                                                                              \
+    hipLaunchKernelGGL((pg_kbuild_kernel<T, M, P>), dim3((unsigned)strips, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, \
+                       ldc, nc, d, symmetric, accumulate, jitter, K, ldk, c0, c1, presc, S, eX, ehp, eK)
+    if (mirror) { if (npf == 2) KB_LAUNCH(true, 2); else if (npf == 4) KB_LAUNCH(true, 4); else KB_LAUNCH(true, 16); }
+    else { if (npf == 2) KB_LAUNCH(false, 2); else if (npf == 4) KB_LAUNCH(false, 4); else KB_LAUNCH(false, 16); }
+#undef KB_LAUNCH
     PG_CHECK(hipGetLastError());
     return 0;
 }

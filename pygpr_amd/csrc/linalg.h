@@ -27,6 +27,9 @@ template <typename T>
 int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0, const ExpBatch* eb = nullptr);
 long pg_potrs_vec_worksize_impl(int n);
 template <typename T> int pg_logdet_t(hipStream_t, int n, const T* L, long ldl, double* out);
+template <typename T>
+int pg_potrs_t(pg_ctx*, hipStream_t, int n, int nrhs, const T* L, long ldl, const T* invD, const T* Minv, long ldm, const T* B, long ldb,
+               T* X, long ldx, T* work, int both);
 template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);
 template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work);
 template <typename T>

@@ -780,6 +780,34 @@ int pg_potrs_vec_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, con
     return 0;
 }
 
+// Matrix right-hand sides: V = L^-1 B (solve_t == 0: the triangular half) or X = K^-1 B = L^-T (L^-1 B).  L^-1 is formed in `work`
+// (n x n) by pg_trtri unless the caller hands one in; both halves are then products of the GEMM core with K ranges: L^-1 is lower
+// triangular, so row tile i of L^-1 B stops at column i + 128 and row tile i of L^-T V starts at row i.
+template <typename T>
+int pg_potrs_t(pg_ctx* ctx, hipStream_t st, int n, int nrhs, const T* L, long ldl, const T* invD, const T* Minv, long ldm, const T* B,
+               long ldb, T* X, long ldx, T* work, int both) {
+    if (n <= 0 || n % PG_PAD || nrhs <= 0 || nrhs % 128) {
+        pg_set_error("pg_potrs: n=%d must be a multiple of %d and nrhs=%d of 128", n, PG_PAD, nrhs);
+        return -2;
+    }
+    int rc;
+    const T* W = Minv;
+    long ldw = ldm;
+    T* V = work;                                   // [n][nrhs] when both halves run
+    if (!W) {
+        if ((rc = pg_trtri_t<T>(ctx, st, n, L, ldl, invD, work, (long)n))) return rc;
+        W = work; ldw = n; V = work + (long)n * n;
+    }
+    GemmP<T> p = gp0<T>();
+    p.M = n; p.N = nrhs; p.K = n; p.A = W; p.lda = ldw; p.B = B; p.ldb = ldb; p.khi = 1;
+    p.C = both ? V : X; p.ldc = both ? nrhs : ldx;
+    if ((rc = pg_gemm<T>(ctx, st, GEMM_NN_128, p))) return rc;
+    if (!both) return 0;
+    p = gp0<T>();
+    p.M = n; p.N = nrhs; p.K = n; p.A = W; p.lda = ldw; p.B = V; p.ldb = nrhs; p.C = X; p.ldc = ldx; p.klo = 1;
+    return pg_gemm<T>(ctx, st, GEMM_TN_128, p);
+}
+
 template <typename T>
 int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv, long ldk) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_lauum: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
@@ -981,6 +1009,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int, const ExpBatch*);       \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
+    template int pg_potrs_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, const T*, long, const T*, long, T*, long, T*, int); \
     template int pg_logdet_t<T>(hipStream_t, int, const T*, long, double*);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
     template int pg_alpha_batched_t<T>(hipStream_t, int, const T*, long, long, const T*, long, T*, long, T*, long, T*, long, int); \

@@ -913,3 +913,28 @@ def test_batched_factorisation(ops, nexp, n, with_inv):
     assert info.tolist() == [0] * nexp
     k = orc.kernel(covs, hp[1], x[0], form="direct") + 1e-7 * np.eye(n)
     np.testing.assert_allclose(np.tril(host(a2[1]))[:n, :n], np.linalg.cholesky(k), atol=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nrhs", [(768, 128), (2304, 384)])
+def test_potrs_matrix_rhs_and_trsm(ops, n, nrhs):
+    """pg_potrs / pg_trsm_lower against scipy's cho_solve / solve_triangular (tc.cholesky_solve with a matrix right-hand side,
+    PyGPR/gpr.py:100,112, loss.py:116), with L^-1 formed inside the call and handed in."""
+    import scipy.linalg as sla
+
+    rng = np.random.default_rng(n)
+    a = spd(n, rng)
+    b = rng.standard_normal((n, nrhs))
+    ad, bd = dev(a), dev(b)
+    invd = ops.potrf_workspace(n, torch.float64)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(ad, invd, info)
+    assert int(info.item()) == 0
+    chol = np.linalg.cholesky(a)
+    x_ref = sla.cho_solve((chol, True), b)
+    v_ref = sla.solve_triangular(chol, b, lower=True)
+    np.testing.assert_allclose(host(ops.potrs(ad, invd, bd)), x_ref, rtol=0, atol=1e-10 * np.abs(x_ref).max())
+    np.testing.assert_allclose(host(ops.potrs(ad, invd, bd, triangular_only=True)), v_ref, rtol=0, atol=1e-11 * np.abs(v_ref).max())
+    minv = ops.zeros(n, n)
+    ops.trtri(ad, invd, minv)
+    np.testing.assert_allclose(host(ops.potrs(None, None, bd, minv=minv)), x_ref, rtol=0, atol=1e-10 * np.abs(x_ref).max())
