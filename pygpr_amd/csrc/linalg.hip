@@ -509,7 +509,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // flag-coupled chain (chainstep.hip) for the panels with at most `sync_rows` rows left -- the chain-bound tail: leaves on the
     // panel stream, the rows below them on the handle's rows stream, coupled by flags in device memory instead of launches.
     // Its rows kernels update a block column by the previous panel too (the window of the left-looking product starts there), so
-    // the per-panel update Sa disappears from the critical path; panels are at most 512 wide there to keep that product
+    // the per-panel update Sa disappears from the critical path; panels are at most 384 wide there (PG_CS_PANEL) to keep that product
     // shorter than a leaf.
     // Measured (MI355X, fp64, build + factor): n = 4096 2.28 -> 1.68 ms, 8192 6.30 -> 5.19, 16384 30.75 -> 29.13 with the last 8192
     // rows coupled (2048: 30.41, 4096: 30.03, 6144: 29.62, 12288: 30.14, all: 31.48 -- while the trailing update still fills the
@@ -521,7 +521,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     hipStream_t rows_stream = ctx->rows;      // the handle's own (capi.hip)
     const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0 && nexp == 1;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
-    static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 512;
+    static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 384;   // round 3, same box: 512 -> 384: n = 4096 1.64 -> 1.60 ms, 8192 5.10 -> 5.03, 16384 equal
     for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, cs_panel) : NBO) pb.push_back(c);
     pb.push_back(n);
     const int npan = (int)pb.size() - 1;

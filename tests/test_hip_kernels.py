@@ -403,8 +403,8 @@ def test_potrf_outer_panel_widths(ops, panel, n):
 
 @pytest.mark.parametrize("n", [8192, 5376])
 def test_potrf_trtri_fused_matches_separate(ops, n):
-    """From n = 5120 the fused call inverts the leading half of the diagonal on the background stream while the
-    Cholesky's tail runs (8192: sixteen 512-column panels; 5376: eleven, the last ragged, trailing part 2816 not a power
+    """pg_potrf_trtri = pg_potrf followed by pg_trtri on the caller's stream (the background-stream overlap of round 1 is off by
+    default, PG_BG_STREAM=1; 8192: every panel on the coupled chain; 5376: the last panel ragged, trailing part not a power
     of two).  The factor must equal the separate call bit for bit, the inverse too when both routes pair the diagonal
     blocks the same way; and the inverse must undo the factor."""
     g = torch.Generator(device="cuda").manual_seed(44)
@@ -630,6 +630,18 @@ def test_grbcm_terms(ops):
 
 
 # ---- flag-coupled chain (chainstep.hip): resident leaf + rows kernels handing over through device flags ------------------------
+CS_PANEL = 384      # width of a coupled panel (PG_CS_PANEL; round 3: 512 -> 384) -- the coupled region is the last 8192 rows
+
+
+def coupled_count(n):
+    """Outer panels that run on the coupled chain for an n x n factorisation with the default schedule."""
+    first = 0
+    nbo = 512 if n <= 10240 else (1024 if n <= 18432 else 2048)
+    while n - first > 8192:
+        first += nbo
+    return -(-(n - first) // CS_PANEL)
+
+
 def _potrf_on_compute_stream(ops, a, dtype=torch.float64):
     """pg_potrf from the caller's current stream (the legacy default stream here: the rows kernels run on the handle's own
     rows stream, so the caller's stream does not matter)."""
@@ -651,7 +663,7 @@ def test_coupled_chain_factor_matches_lapack(ops, n):
     a = spd(n, rng)
     ad, invd, info, coupled = _potrf_on_compute_stream(ops, a)
     assert info == 0
-    assert coupled == -(-n // 512), "the coupled chain did not run"
+    assert coupled == coupled_count(n), "the coupled chain did not run"
     chol = np.linalg.cholesky(a)
     np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
     blocks = host(invd[: n * 128]).reshape(n // 128, 128, 128)
@@ -668,7 +680,7 @@ def test_coupled_chain_tail_of_a_larger_matrix(ops):
     rng = np.random.default_rng(7)
     a = spd(n, rng)
     ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
-    assert info == 0 and coupled == 16
+    assert info == 0 and coupled == coupled_count(n)
     ops.set_lookahead(0)
     try:
         ref = dev(a)
@@ -700,7 +712,7 @@ def test_coupled_chain_fp32(ops):
     rng = np.random.default_rng(11)
     a = spd(n, rng, cond_shift=4.0)
     ad, _, info, coupled = _potrf_on_compute_stream(ops, a, torch.float32)
-    assert info == 0 and coupled == 8
+    assert info == 0 and coupled == coupled_count(n)
     l = np.tril(host(ad).astype(np.float64))
     assert np.abs(l @ l.T - a).max() / np.abs(a).max() < 5e-5
 
@@ -717,7 +729,7 @@ def test_coupled_chain_fused_inverse(ops):
     ops.potrf_trtri(ad, ops.potrf_workspace(n, torch.float64), info, minv)
     coupled = ops.last_coupled_panels()
     torch.cuda.synchronize()
-    assert int(info.item()) == 0 and coupled == 8
+    assert int(info.item()) == 0 and coupled == coupled_count(n)
     chol = np.linalg.cholesky(a)
     np.testing.assert_allclose(np.tril(host(minv)), np.linalg.inv(chol), atol=1e-9)
 
@@ -735,7 +747,7 @@ def test_coupled_chain_from_a_side_stream_caller(ops):
         ops.potrf(ad, ops.potrf_workspace(n, torch.float64), info)
         coupled = ops.last_coupled_panels()
         lower = torch.tril(ad).cpu().numpy()          # on the side stream, behind the factorisation
-    assert int(info.item()) == 0 and coupled == 6
+    assert int(info.item()) == 0 and coupled == coupled_count(n)
     np.testing.assert_allclose(lower, np.linalg.cholesky(a), atol=1e-11)
 
 
@@ -751,7 +763,7 @@ def test_coupled_chain_switch_and_probe(ops):
         for on in (1, 0):
             ops.set_coupled_chain(on)
             ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
-            assert info == 0 and (coupled == 6 if on else coupled == 0)
+            assert info == 0 and (coupled == coupled_count(n) if on else coupled == 0)
             outs.append(np.tril(host(ad)))
     finally:
         ops.set_coupled_chain(1)
@@ -814,7 +826,7 @@ def test_coupled_chain_timeout_reports_and_switches_to_the_classic_chain(ops, fo
     a = spd(n, np.random.default_rng(23))
     before = ops.chain_timeouts()
     _, _, info, coupled = _potrf_on_compute_stream(ops, a)
-    assert coupled == 6 and info == -1
+    assert coupled == coupled_count(n) and info == -1
     assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0
     ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
     assert info == 0 and coupled == 0

@@ -469,8 +469,8 @@ def test_large_d_through_the_class_surface():
 
 
 def test_headline_size_properties():
-    """BASELINE config 3's size, N=16384 D=8 fp64 -- the NBO = 1024 schedule with the background split that bench.py
-    times (16 outer panels): (i) directional derivative against central differences, (ii) K alpha = y through a
+    """BASELINE config 3's size, N=16384 D=8 fp64 -- the schedule bench.py times (1024-column outer panels, the last 8192 rows
+    on the flag-coupled chain): (i) directional derivative against central differences, (ii) K alpha = y through a
     prediction at training inputs, (iii) the fused pg_potrf_trtri factor equals the separate pg_potrf bit for bit and
     its inverse undoes it."""
     from pygpr_amd._ops import get_ops

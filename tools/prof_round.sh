@@ -1,12 +1,18 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof2; rm -rf $O; mkdir -p $O
+RD=${PG_ROUND:-r03}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$RD; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench.log 2>&1; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss -- python3 $R/tools/probe_eval_single_stream.py > $O/ss.log 2>&1; echo "ss rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 $R/tools/probe_eval_once.py > $O/pmc_f.log 2>&1; echo "pmc_f rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 $R/tools/probe_eval_once.py > $O/pmc_w.log 2>&1; echo "pmc_w rc=$?"
-python3 $R/tools/pmc_summary.py $O/pmc_f $O/pmc_w > $O/r02_pmc_eval_traffic.json; echo "summary rc=$?"
+python3 $R/tools/pmc_summary.py $O/pmc_f $O/pmc_w > $O/${RD}_pmc_eval_traffic.json; echo "summary rc=$?"
 PG_NO_PY_ATEXIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/teardown -- python3 $R/tools/probe_potrf.py 8192 potrf_only > $O/teardown.log 2>&1; echo "teardown rc=$?"
-f=$(find $O/bench -name "*kernel_stats.csv" | head -1); cp $f $O/r02_kernel_stats_bench.csv; python3 $R/tools/stats_summary.py $f > $O/r02_kernel_stats_bench.txt
-f=$(find $O/ss -name "*kernel_stats.csv" | head -1); cp $f $O/r02_kernel_stats_ss.csv; python3 $R/tools/stats_summary.py $f > $O/r02_kernel_stats_ss.txt
+f=$(find $O/bench -name "*kernel_stats.csv" | head -1); cp $f $O/${RD}_kernel_stats_bench.csv; python3 $R/tools/stats_summary.py $f > $O/${RD}_kernel_stats_bench.txt
+f=$(find $O/ss -name "*kernel_stats.csv" | head -1); cp $f $O/${RD}_kernel_stats_ss.csv; python3 $R/tools/stats_summary.py $f > $O/${RD}_kernel_stats_ss.txt
 tail -3 $O/teardown.log
-rm -rf $O/bench $O/ss $O/pmc_f $O/pmc_w $O/teardown
+# the covariance build on its own: kernel trace + FETCH / WRITE passes of tools/probe_kbuild_once.py (lower-only and mirrored, N = 16384, D = 8)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kb -- python3 $R/tools/probe_kbuild_once.py > $O/kb.log 2>&1; echo "kb rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/kb_f -- python3 $R/tools/probe_kbuild_once.py > $O/kb_f.log 2>&1; echo "kb_f rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/kb_w -- python3 $R/tools/probe_kbuild_once.py > $O/kb_w.log 2>&1; echo "kb_w rc=$?"
+python3 $R/tools/kbuild_summary.py $O/kb $O/kb_f $O/kb_w > $O/${RD}_kernel_build_hbm.json; echo "kb summary rc=$?"
+rm -rf $O/bench $O/ss $O/pmc_f $O/pmc_w $O/teardown $O/kb $O/kb_f $O/kb_w
