@@ -437,24 +437,41 @@ def main():
                 best = min(best, e0.elapsed_time(e1))
             return best
 
-        t_build = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, jitter=1e-7), 10)
+        # the covariance build: FOUR launches back to back between two events, so that the figure is the kernel's duration
+        # (what rocprofv3 --kernel-trace reports: profiles/r03_kernel_build_hbm.json) and not one launch's latency on top of it
+        def build_x4(lower):
+            for _ in range(4):
+                ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=lower, jitter=1e-7)
+
+        t_build = timed(lambda: build_x4(False), 5) / 4
         bytes_build = 8.0 * n * n + 8.0 * n * d
         out["roofline_kernel_build"] = {
             "bound": "hbm", "achieved": bytes_build / t_build / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_build / t_build / 1e6 / HBM_PEAK_GBS, "ms": t_build, "algorithmic_bytes": bytes_build,
+            "kernel": "pg_kbuild_kernel<double, true, 2> (mirrored symmetric build); lower_only: <double, false, 2>, the build the "
+                      "factorisation's path uses", "timing": "HIP events around 4 back-to-back launches / 4, best of 5",
         }
-        t_lower = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 10)
+        t_lower = timed(lambda: build_x4(True), 5) / 4
         bytes_lower = 4.0 * n * (n + 64) + 8.0 * n * d
         out["roofline_kernel_build"]["lower_only"] = {"ms": t_lower, "algorithmic_bytes": bytes_lower,
                                                       "achieved": bytes_lower / t_lower / 1e6,
                                                       "frac": bytes_lower / t_lower / 1e6 / HBM_PEAK_GBS}
+        kbp = os.path.join(ROOT, "profiles", "r03_kernel_build_hbm.json")
+        if n == 16384 and os.path.exists(kbp):
+            with open(kbp) as fh:
+                kj = json.load(fh)
+            if kj.get("build", {}).get("src_sha16") == out["build"]["src_sha16"]:
+                out["roofline_kernel_build"]["traffic"] = kj["mirrored"]["hbm_bytes_pmc"]
+                out["roofline_kernel_build"]["lower_only"]["traffic"] = kj["lower_only"]["hbm_bytes_pmc"]
+                out["roofline_kernel_build"]["traffic_source"] = "profiles/r03_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
+        t_lower_single = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)   # one launch, for the legs below
 
         def fac():
             ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7)
             ops.potrf(a, invd, info)
 
         def chol_leg(nn):
-            t = timed(fac, 3) - t_lower * (nn / float(n)) ** 2
+            t = timed(fac, 3) - t_lower_single * (nn / float(n)) ** 2
             return {"n": nn, "ms": t, "tflops": nn ** 3 / 3.0 / t / 1e9,
                     "frac_of_fp64_matrix_peak": nn ** 3 / 3.0 / t / 1e9 / FP64_MATRIX_PEAK_TFLOPS}
 
@@ -558,6 +575,47 @@ def main():
             "check": check_committee(g4, xs[:mb].cpu(), hp4.numpy()),
         }
         del g4, xs
+
+    # ---- experts together (round 3): Exact_GP.update() of a batched model -- covariance build + Cholesky + L^-1 + alpha for all
+    # experts -- as ONE batched call per step of the blocked algorithm against one expert after the other (the round-2 loop, each
+    # expert on the single-model schedule with its coupled chain).  PyGPR/gpr.py:65-74 factorises the batch in one tc.cholesky.
+    if legs:
+        from pygpr_amd import gpr as _gpr
+
+        def fit_ms(nc_, n_, d_, batched):
+            keep = _gpr._BATCH_MAX_N
+            _gpr._BATCH_MAX_N = keep if batched else 0
+            try:
+                rng_ = np.random.default_rng(3)
+                x_ = rng_.random((nc_, n_, d_))
+                y_ = np.sin(-x_.sum(-1)) + 0.1 * rng_.standard_normal((nc_, n_))
+                gp_ = pg.Exact_GP(torch.from_numpy(x_), torch.from_numpy(y_), cov, eager_inverse=True)
+                gp_.set_params(torch.from_numpy(np.tile(np.concatenate([[1.0], np.full(d_, 0.5), [0.1]]), (nc_, 1))))
+                gp_.update()
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(3):
+                    gp_.need_upd = True
+                    t0_ = time.perf_counter()
+                    gp_.update()
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0_)
+                assert (gp_._bat is not None) == batched
+                del gp_
+                torch.cuda.empty_cache()
+                return 1e3 * best
+            finally:
+                _gpr._BATCH_MAX_N = keep
+
+        et = {}
+        for name, (nc_, n_, d_) in (("nc10_n100", (10, 100, 3)), ("nc8_n2048", (8, 2048, 16)), ("nc8_n4096", (8, 4096, 16)),
+                                    ("cfg4_nc8_n9216", (8, 9216, 16))):
+            tb_, ts_ = fit_ms(nc_, n_, d_, True), fit_ms(nc_, n_, d_, False)
+            et[name] = {"batched_ms": tb_, "one_after_the_other_ms": ts_, "speedup": ts_ / tb_,
+                        "tflops_batched": nc_ * 2.0 * float(n_) ** 3 / 3.0 / (tb_ * 1e-3) / 1e12}
+        et["what"] = ("Exact_GP.update(), eager inverse: covariance build + Cholesky + L^-1 + alpha for nc experts of n points, best of 3; "
+                      "batched = pg_build_potrf_trtri_batched + pg_alpha_batched (every launch covers all experts)")
+        out["experts_together"] = et
 
     # ---- BASELINE config 5: grBCM, 8 experts x (1024 + 32768) points, Matern-5/2, fp32, shared-hp co-training objective
     # sum_c NLML_c and its gradient (GRBCM_MLE): 1 warm-up + 3 evaluations.  At N = 1 the 8 experts run one after another
