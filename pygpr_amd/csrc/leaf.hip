@@ -606,6 +606,227 @@ __device__ __forceinline__ void leaf2_body(char* smem_raw, T* __restrict__ A, lo
 #undef LTL
 }
 
+// ------------------------------------------------------------------------------------------------
+// Leaf, third form (round 3): the panel solve and the first update column leave the pivot loop.
+// The second form runs every panel row through the register-resident pivot loop (a row per lane), writes the rows back to LDS,
+// meets at a barrier and only then forms the next column block's update by MFMA -- a step is pivot loop (1.4 us) + LDS round trip of
+// 128 rows (1.2) + update column (0.5) + two barriers = 3.4 us, stamped in-kernel.  Here ONE wave factors the 16 x 16 diagonal block
+// alone (sixteen rows + sixteen identity rows: D and D^-1, square-root-free chain), and everything below it is two chained MFMA
+// products per 16-row tile that never leave the accumulator layout:
+//     X_t^T = D^-1 A_t^T          (A operand D^-1, B operand the tile as stored)        -> lane holds X_t[l & 15][k(r)], r = 0..3
+//     T_t  -= X_t X_0^T           (A operand = those four registers, B operand = the same four of tile 0, recomputed per wave)
+// because the C/D layout of the first product IS the A/B fragment layout of the second (k and the tile row swap roles).  The wave
+// that owns tile 0 -- the next diagonal block -- goes straight on to factor it while the others finish the step (their tiles, then
+// the deferred trailing update and the inverse's block row): per step the critical wave runs factor (1.0-1.4 us) + one tile's
+// chain (0.4) + two barriers.
+// ------------------------------------------------------------------------------------------------
+// The third form's serial core as a function of its own (NOT inlined): inside the 168-VGPR / 106-SGPR leaf kernel the compiler
+// had two scalar registers left for the loop's broadcasts (v_readlane -> s[0:1] -> v_fma, fifteen times per column through the
+// same pair: 2.0 us per step); compiled on its own it pipelines them through as many pairs as it likes (1.04 us in isolation,
+// tools/micro/tallstep.hip).  One wave: lanes 0-15 the block's rows, lanes 16-31 identity rows (they leave as D^-1).
+// Returns the first non-positive pivot's column (16: none).
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) float lds_f32;
+template <typename T> struct LdsPtr;
+template <> struct LdsPtr<double> { typedef lds_f64* type; };
+template <> struct LdsPtr<float> { typedef lds_f32* type; };
+template <typename T>
+__device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typename LdsPtr<T>::type Dv, int lane) {
+    const int fr = lane & 15;
+    const bool is_diag = lane < 16, is_ident = lane >= 16 && lane < 32;
+    T row[16], piv[16];
+    // every lane loads its (fr-th) row unconditionally, all sixteen values in flight, and only then selects: written as
+    // `is_diag ? D[..] : ident` the compiler put each load behind its own exec-mask branch (sixteen serial LDS round trips)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = D[fr * LD + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(row[c]));
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = is_diag ? row[c] : ((is_ident && c == fr) ? (T)1 : (T)0);
+    int first_bad = 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        piv[c] = bcast_lane(row[c], c);                         // wave-uniform
+        first_bad = (piv[c] > (T)0) ? first_bad : min(first_bad, c);
+        const T w = row[c] * recip(piv[c]);
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) row[k] -= row[c] * bcast_lane(w, k);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] *= inv_sqrt(piv[c]);
+    if (first_bad == 16) {
+        if (is_diag) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) D[fr * LD + c] = row[c];      // (right of the diagonal: masked where L leaves the workgroup)
+        } else if (is_ident) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Dv[c * DLD + fr] = row[c];    // column fr of D^-1
+        }
+    }
+    return first_bad;
+}
+
+template <typename T, bool WT>
+__device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
+                                           int* __restrict__ info, int col0, long long* tlog = nullptr) {
+#define LTL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((127 * lda + 128) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(inv, 0, inv ? (int)((127 * ldi + 128) * sizeof(T)) : 0, 0x00020000);
+    T* S = reinterpret_cast<T*>(smem_raw);
+    T* Dinv = S + NB * LD;                                  // [8][16][DLD]
+    int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    typedef typename Mfma<T>::acc_t acc_t;
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+
+    if (*info != 0) return;
+    if (tid == 0) fail = 0;
+    {   // lower triangle -> LDS, two columns per thread, 64 pairs per row; all loads are issued before the first use
+        constexpr int NLD = (NB * NB / 2 + NTH - 1) / NTH;
+        pair_t v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
+            v[u] = pair_t{(T)0, (T)0};
+            if (idx < NB * NB / 2 && k <= i) {
+                if (WT) v[u] = ld_pair_wt(A, rA, (long)i * lda + k);
+                else v[u] = *reinterpret_cast<const pair_t*>(A + (long)i * lda + k);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * NTH, i = idx >> 6, k = (idx & 63) * 2;
+            if (k + 1 > i) v[u][1] = (T)0;
+            if (idx < NB * NB / 2) *reinterpret_cast<pair_t*>(S + i * LD + k) = v[u];
+        }
+    }
+    __syncthreads();
+    LTL(16);
+    const bool want_inv = inv != nullptr;
+    acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
+    for (int jb = 0; jb < NB / 16; ++jb) {
+        const int c0 = jb * 16, r0 = c0 + 16;
+        if (wave == 0) {
+            // ---- F: the diagonal block alone.  lanes 0-15: its rows; lanes 16-31: identity rows, which leave the loop as D^-1
+            if (jb == 3) { LTL(35); if (tlog && threadIdx.x == 0) tlog[37] = clock64(); }
+            const int first_bad = leaf3_factor_diag<T>((typename LdsPtr<T>::type)(S + c0 * LD + c0), (typename LdsPtr<T>::type)(Dinv + jb * 16 * DLD),
+                                                       lane);
+            if (jb == 3) { __builtin_amdgcn_s_waitcnt(0xc07f); LTL(36); if (tlog && threadIdx.x == 0) tlog[38] = clock64(); }
+            if (first_bad < 16 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
+        }
+        __syncthreads();                                               // B: D and D^-1 of this step are published
+        LTL(17 + 2 * jb);
+        if (fail) return;
+        if (r0 >= NB) break;
+        const int nt = (NB - r0) / 16;
+        // ---- M: panel solve + first update column, one 16-row tile per wave, all in MFMA fragments
+        if (wave < nt) {
+            const int t = wave;
+            T df[4], a0[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                df[q] = Dinv[jb * 16 * DLD + fr * DLD + 4 * q + fk];            // A operand: D^-1[fr][4q + fk]
+                a0[q] = S[(r0 + fr) * LD + c0 + 4 * q + fk];                    // B operand: A_0[fr][4q + fk] (= A_0^T[4q + fk][fr])
+            }
+            acc_t ct;                                                            // T_t in C layout
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x0[r] = (T)0;
+                ct[r] = S[(r0 + 16 * t + Mfma<T>::row(lane, r)) * LD + r0 + fr];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x0 = Mfma<T>::run(df[q], a0[q], x0);    // X_0^T: lane holds X_0[fr][row(lane, r)]
+            acc_t xt = x0;
+            if (t > 0) {
+                T at[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) at[q] = S[(r0 + 16 * t + fr) * LD + c0 + 4 * q + fk];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xt[r] = (T)0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xt = Mfma<T>::run(df[q], at[q], xt);
+            }
+            acc_t u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = (T)0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u = Mfma<T>::run(xt[r], x0[r], u);      // sum over k = row(lane, r): X_t[i][k] X_0[j][k]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(r0 + 16 * t + Mfma<T>::row(lane, r)) * LD + r0 + fr] = ct[r] - u[r];
+            if (t > 0 || nt == 1) {                                              // the panel's rows of L (tile 0: see below)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(r0 + 16 * t + fr) * LD + c0 + Mfma<T>::row(lane, r)] = xt[r];
+            }
+        }
+        __syncthreads();                                               // B': every tile's X and updated column are in LDS
+        LTL(18 + 2 * jb);
+        if (wave == 0) {
+            // tile 0's rows of L go out only now: the other waves read the unsolved tile 0 during M (with a single tile nobody
+            // does, and the inverse's last block row -- formed in the slot below -- already reads these rows: stored in M then)
+            if (nt > 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(r0 + fr) * LD + c0 + Mfma<T>::row(lane, r)] = x0[r];
+            }
+        } else {
+            // ---- beside the next step's factor: the rest of this step's trailing update (tiles (ti, tj), 1 <= tj <= ti), block row
+            // jb of the inverse (its D^-1 exists since B), and -- in the last such slot -- the sums of the inverse's last block row
+            const int nrest = nt * (nt - 1) / 2;
+            const int nx = want_inv ? jb : 0;
+            const bool last = want_inv && jb == NB / 16 - 2;           // after it only the last diagonal block is factored
+            for (int w = wave - 1; w < nrest + nx + (last ? 1 : 0); w += NWV - 1) {
+                if (last && w == nrest + nx) {
+                    inv_tile_sum<T>(S, Dinv, jb + 1, jb, lane);        // q = 6: L[7][6] Dinv[6]
+                    continue;
+                }
+                if (w < nrest) {
+                    int uu = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+                    while (uu * (uu + 1) / 2 > w) --uu;
+                    while ((uu + 1) * (uu + 2) / 2 <= w) ++uu;
+                    const int ti = uu + 1, tj = w - uu * (uu + 1) / 2 + 1;
+                    lds_tile_mm<T, true>(S + (r0 + ti * 16) * LD + r0 + tj * 16, LD, S + (r0 + ti * 16) * LD + c0, LD,
+                                         S + (r0 + tj * 16) * LD + c0, LD, 16, (T)-1, (T)1, lane);
+                } else {
+                    inv_tile<T>(S, Dinv, jb, w - nrest, lane);
+                    if (last) inv_tile_sum<T>(S, Dinv, jb + 1, w - nrest, lane);
+                }
+            }
+        }
+    }
+    // the loop ends behind B of the last step: L is complete; of the inverse only the last block row's final products are missing
+    if (want_inv) {
+        for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);
+    }
+    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+        if (k > i) v[0] = (T)0;
+        if (k + 1 > i) v[1] = (T)0;
+        if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+        else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+    }
+    if (!want_inv) return;
+    __syncthreads();
+    LTL(34);
+    for (int idx = tid; idx < NB * 64; idx += NTH) {
+        const int i = idx >> 6, k = (idx & 63) * 2;
+        const int pb = i >> 4, qb = k >> 4, ii = i & 15;
+        pair_t v = {(T)0, (T)0};
+        if (qb == pb) {
+            const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
+            v[0] = (k <= i) ? Dv[0] : (T)0;
+            v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
+        } else if (qb < pb) {
+            const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
+            v[0] = Xt[0];
+            v[1] = Xt[1];
+        }
+        if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
+        else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+    }
+#undef LTL
+}
+
 template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf2_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                                        int* __restrict__ info, int col0, int ablate, long eA, long eInv) {
@@ -647,6 +868,42 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
     }
 }
 
+// The third form as kernels of its own: sharing a kernel with the second form (a run-time switch between two inlined bodies) left
+// the pivot loop two scalar registers for its broadcasts.
+template <typename T, bool WT>
+__global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
+                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
+    if (threadIdx.x == 0) {
+        if (!cs_spin_ge(ready, want, tmo)) atomicCAS(info, 0, -1);
+        if (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
+    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog);
+    if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tlog && threadIdx.x == 0) tlog[3] = wall_clock64();
+    if (threadIdx.x == 0) {
+        if (!WT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(NTH) void pg_leaf3_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi, int* __restrict__ info,
+                                                       int col0, long eA, long eInv) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    leaf3_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0);
+}
+
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
                                        const CsWait& tmo) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
@@ -655,6 +912,10 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
@@ -667,7 +928,15 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     //                   no gain inside the kernel: a step's 2.9-3.5 us are the chain (1.4), the rows' LDS round trip (1.2) and
     //                   two barriers, and the shorter chain only moves the waiting: n = 4096 1.63 -> 1.69 ms
     static const int abl = ((getenv("PG_LEAF_PROG") && atoi(getenv("PG_LEAF_PROG"))) ? 0 : 16) |
-                           ((getenv("PG_LEAF_LDL") && atoi(getenv("PG_LEAF_LDL"))) ? 0 : 32);
+                           ((getenv("PG_LEAF_LDL") && atoi(getenv("PG_LEAF_LDL"))) ? 0 : 32) |
+                           ((getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3"))) ? 0 : 64);           // third form (default); PG_LEAF3=0: second
+    long long* tl = getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr;
+    if (abl & 64) {
+        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl);
+        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl);
+        PG_CHECK(hipGetLastError());
+        return 0;
+    }
     if (wt) hipLaunchKernelGGL((pg_leaf2s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
                                getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr, abl);
     else hipLaunchKernelGGL((pg_leaf2s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
@@ -685,12 +954,20 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
     static const int form = getenv("PG_LEAF") ? atoi(getenv("PG_LEAF")) : 2;   // 1: round-1 leaf (A / B / C phases), 2: fused tall-panel step
     if (!(getenv("PG_LEAF_PROG") && atoi(getenv("PG_LEAF_PROG")))) ablate ^= 16;     // default: round 2's data movement (bit 4 set);
     if (!(getenv("PG_LEAF_LDL") && atoi(getenv("PG_LEAF_LDL")))) ablate ^= 32;       // a caller's bit asks for the other form
+    if (!(getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3")))) ablate ^= 64;           // third form unless PG_LEAF3=0 (or the caller's bit 6)
     if (!attr_done) {
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
+    }
+    if ((ablate & 64) && form != 1 && !(ablate & 15)) {      // third form (no ablation switches)
+        hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv);
+        PG_CHECK(hipGetLastError());
+        return 0;
     }
     if (form == 1) hipLaunchKernelGGL(pg_leaf_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate, eA, eInv);
     else hipLaunchKernelGGL(pg_leaf2_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, ablate, eA, eInv);

@@ -55,6 +55,19 @@ template <> __device__ __forceinline__ void tall_step<1>(double (&row)[16]) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] *= inv_sqrt(piv[c]);
 }
+// V5: V1 with each pivot's square root taken inside its own iteration (off the chain: nothing waits for it), so that the sixteen
+// pivots do not stay in scalar registers until the end (32 SGPRs live across the loop left the broadcasts two pairs to go through)
+template <> __device__ __forceinline__ void tall_step<5>(double (&row)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double piv = bcast_lane(row[c], c);
+        const double w = row[c] * recip(piv);
+        const double rs = inv_sqrt(piv);
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) row[k] -= row[c] * bcast_lane(w, k);
+        row[c] *= rs;
+    }
+}
 // V2: two columns per pivot step (2 x 2 diagonal blocks, one reciprocal of the determinant per pair)
 template <> __device__ __forceinline__ void tall_step<2>(double (&row)[16]) {
     double pa[8], pb[8], pdet[8];
@@ -102,6 +115,48 @@ template <> __device__ __forceinline__ void tall_step<3>(double (&row)[16]) {
     }
 }
 
+// V4: no scalar registers at all -- broadcasts by DPP row_newbcast inside each row of sixteen lanes.  Every 16-lane row of the wave
+// carries its own copy of the diagonal block's sixteen rows (register set d[]) AND sixteen more rows (register set x[]: identity or
+// panel rows); lane k of a row broadcasts to its row only, which is all a row needs.  Two updates per broadcast instead of one, but
+// no v_readlane -> SGPR -> VALU hop (and no dependence on how many scalar registers the surrounding kernel has left).
+template <int K> __device__ __forceinline__ double row_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int C> struct ColStep {
+    static __device__ __forceinline__ void run(double (&d)[16], double (&x)[16], double (&piv)[16]) {
+        piv[C] = row_bcast<C>(d[C]);
+        const double y = recip(piv[C]);
+        const double w = d[C] * y;
+        upd<C + 1>(d, x, w);
+        ColStep<C + 1>::run(d, x, piv);
+    }
+    template <int Kk> static __device__ __forceinline__ void upd(double (&d)[16], double (&x)[16], double w) {
+        if constexpr (Kk < 16) {
+            const double wk = row_bcast<Kk>(w);
+            d[Kk] -= d[C] * wk;
+            x[Kk] -= x[C] * wk;
+            upd<Kk + 1>(d, x, w);
+        }
+    }
+};
+template <> struct ColStep<16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double (&)[16]) {} };
+template <> __device__ __forceinline__ void tall_step<4>(double (&row)[16]) {
+    // lanes of every 16-lane row: d = the diagonal block's row (lane & 15), x = this lane's own extra row (here: the input row)
+    double d[16], piv[16];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = __shfl(row[c], lane & 15, 64);      // set-up only (the leaf would load both sets from LDS)
+    ColStep<0>::run(d, row, piv);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const double rs = inv_sqrt(piv[c]); row[c] *= rs; d[c] *= rs; }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[c] = d[c];                           // report the diagonal rows from lanes 0-15 like the other variants
+    }
+}
+
 template <int V> __global__ __launch_bounds__(256) void bench(const double* __restrict__ in, double* __restrict__ out, long long* t, int reps) {
     const int lane = threadIdx.x & 63;
     double orig[16], row[16];
@@ -109,15 +164,17 @@ template <int V> __global__ __launch_bounds__(256) void bench(const double* __re
     for (int c = 0; c < 16; ++c) orig[c] = in[lane * 16 + c];
     double sink = 0.0;
     const long long w0 = wall_clock64(), c0 = clock64();
+    long long cfirst = 0;
 #pragma unroll 1
     for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) { row[c] = orig[c] + sink; asm volatile("" : "+v"(row[c])); }   // sink: every step waits for the one before
         tall_step<V>(row);
         sink = row[15] * 0.0;          // (finite inputs: exactly 0, but a true dependence on the step's last value)
+        if (rep == 0) { asm volatile("" : "+v"(sink)); cfirst = clock64() - c0; }
     }
     const long long w1 = wall_clock64(), c1 = clock64();
-    if (threadIdx.x == 0) { t[0] = (c1 - c0) / reps; t[1] = (w1 - w0) * 10 / reps; }      // shader clocks, ns
+    if (threadIdx.x == 0) { t[0] = (c1 - c0) / reps; t[1] = (w1 - w0) * 10 / reps; t[2] = cfirst; }      // shader clocks, ns, clocks of the FIRST (cold-code) step
     if (threadIdx.x < 64 && blockIdx.x == 0)
         for (int c = 0; c < 16; ++c) out[lane * 16 + c] = row[c];
 }
@@ -174,6 +231,55 @@ template <int V, int W> __global__ __launch_bounds__(768) void phase_bench(const
     if (tid < 64) out[tid] = S[tid * LD + tid];
 }
 
+// The third leaf's structure in isolation: 768 threads; per repetition wave 0 runs the square-root-free step on LDS-resident rows
+// (loads, loop, stores) while the other eleven waves either wait at the barrier (BUSY = 0) or run LDS-fed fp64 MFMA tiles (BUSY = 1),
+// or every wave runs the step on its own copy (BUSY = 2: does company on other SIMDs, fetching the same code, change wave 0's time?).
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int BUSY> __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void struct_bench(const double* __restrict__ in, double* __restrict__ out, long long* t, int reps) {
+    __shared__ double S[128 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a SCALAR branch below
+    for (int i = tid; i < 128 * LD; i += 768) S[i] = 0.01 * ((i * 7) % 13);
+    __syncthreads();
+    for (int i = tid; i < 256; i += 768) S[(i >> 4) * LD + (i & 15)] = in[i];      // the SPD diagonal block (rows 0-15)
+    __syncthreads();
+    long long acc = 0, first = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        if (wave == 0 || BUSY == 2) {
+            double row[16];
+            const long long c0 = clock64();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = S[(lane & 15) * LD + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(row[c]));
+            tall_step<5>(row);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(row[c]));
+            if (wave == 0 && lane >= 32 && lane < 48) {                               // results go to a scratch block (the input stays)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) S[(32 + (lane & 15)) * LD + 16 + c] = row[c];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const long long dt = clock64() - c0;
+            if (wave == 0) { acc += dt; if (rep == 0) first = dt; }
+        } else if (BUSY == 1) {
+            // LDS-fed MFMA tiles like the leaf's deferred update: 6 tiles of K = 16 per wave and repetition
+            const int fr = lane & 15, fk = lane >> 4;
+            for (int tile = 0; tile < 6; ++tile) {
+                d4 a4 = {0, 0, 0, 0};
+                const double* Ap = S + (48 + 16 * (tile % 5) + fr) * LD + 32;
+                const double* Bp = S + (64 + fr) * LD + 48;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * q + fk], Bp[4 * q + fk], a4, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(96 + fk + 4 * r) * LD + 64 + 16 * (wave % 4) + fr] = a4[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { t[0] = acc / reps; t[1] = first; }
+    if (tid < 64) out[tid] = S[(32 + (tid & 15)) * LD + 16 + (tid & 15)];
+}
+
 // dependent-chain probes: cycles per dependent op
 __global__ void chain_probe(double* out, long long* t) {
     double x = 1.0 + 1e-9 * threadIdx.x, y = 0.999999;
@@ -225,13 +331,17 @@ int main() {
     printf("dependent chain, shader clocks per op (x1000 iterations of 16): v_fma_f64 %.1f  v_rsq_f64+add %.1f  readlane pair + fma %.1f\n", ht[0] / 1000.0, ht[1] / 1000.0, ht[2] / 1000.0);
 #define RUN(V)                                                                                                     \
     { bench<V><<<1, 256>>>(din, dout, dt, 2000); hipDeviceSynchronize();                                            \
-      hipMemcpy(ht, dt, 16, hipMemcpyDeviceToHost); hipMemcpy(o.data(), dout, o.size() * 8, hipMemcpyDeviceToHost); \
+      hipMemcpy(ht, dt, 24, hipMemcpyDeviceToHost); hipMemcpy(o.data(), dout, o.size() * 8, hipMemcpyDeviceToHost); \
       double err = 0; for (int l = 0; l < 64; ++l) for (int c = 0; c < 16; ++c) if (l >= 16 || c <= l) err = fmax(err, fabs(o[l * 16 + c] - ref[l * 16 + c])); \
-      printf("variant %d: %lld clock64 ticks, %lld ns per 16-column step (%.0f ns per column), max abs err vs long-double Cholesky %.2e\n", V, ht[0], ht[1], ht[1] / 16.0, err); }
-    RUN(0) RUN(1) RUN(2) RUN(3)
+      printf("variant %d: %lld clock64 ticks, %lld ns per 16-column step (%.0f ns per column), FIRST step of the launch (cold instruction cache) %lld ticks, max abs err vs long-double Cholesky %.2e\n", V, ht[0], ht[1], ht[1] / 16.0, ht[2], err); }
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
 #define PRUN(V, W)                                                                                                  \
     { phase_bench<V, W><<<1, 768>>>(din, dout, dt, 400); hipDeviceSynchronize(); hipMemcpy(ht, dt, 32, hipMemcpyDeviceToHost); \
       printf("phase V%d W%d: LDS reads %lld ns, 16-column loop %lld ns, LDS writes + drain %lld ns, barrier %lld ns\n", V, W, ht[0], ht[1], ht[2], ht[3]); }
-    PRUN(0, 0) PRUN(0, 1) PRUN(0, 2) PRUN(1, 0) PRUN(1, 1)
+#define SRUN(B)                                                                                                     \
+    { struct_bench<B><<<1, 768>>>(din, dout, dt, 400); hipDeviceSynchronize(); hipMemcpy(ht, dt, 16, hipMemcpyDeviceToHost); \
+      printf("leaf-3 structure, companions %s: wave 0's step (LDS loads + loop + stores) %lld shader clocks per repetition, first %lld\n", \
+             B == 0 ? "idle at the barrier" : (B == 1 ? "running LDS-fed MFMA tiles" : "running the same step"), ht[0], ht[1]); }
+    SRUN(0) SRUN(1) SRUN(2)
     return 0;
 }
