@@ -19,6 +19,7 @@
 // LDS: S[128][130] + 8 x [16][18] diagonal inverses, all in the dynamic region.
 #include "leaf.h"
 #include "chainstep.h"
+#include <algorithm>
 #include <cstdlib>
 
 #define NB 128
@@ -631,7 +632,7 @@ template <typename T> struct LdsPtr;
 template <> struct LdsPtr<double> { typedef lds_f64* type; };
 template <> struct LdsPtr<float> { typedef lds_f32* type; };
 template <typename T>
-__device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typename LdsPtr<T>::type Dv, int lane) {
+__device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typename LdsPtr<T>::type Dv, int lane, bool store) {
     const int fr = lane & 15;
     const bool is_diag = lane < 16, is_ident = lane >= 16 && lane < 32;
     T row[16], piv[16];
@@ -654,7 +655,7 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] *= inv_sqrt(piv[c]);
-    if (first_bad == 16) {
+    if (first_bad == 16 && store) {
         if (is_diag) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) D[fr * LD + c] = row[c];      // (right of the diagonal: masked where L leaves the workgroup)
@@ -668,7 +669,7 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
 
 template <typename T, bool WT>
 __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                           int* __restrict__ info, int col0, long long* tlog = nullptr) {
+                                           int* __restrict__ info, int col0, long long* tlog = nullptr, int nf3 = 1) {
 #define LTL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((127 * lda + 128) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(inv, 0, inv ? (int)((127 * ldi + 128) * sizeof(T)) : 0, 0x00020000);
@@ -704,16 +705,18 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     __syncthreads();
     LTL(16);
     const bool want_inv = inv != nullptr;
+    const int NF3 = nf3;                                    // waves that run the factor's instructions (wave 0 for real)
     acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
-        if (wave == 0) {
-            // ---- F: the diagonal block alone.  lanes 0-15: its rows; lanes 16-31: identity rows, which leave the loop as D^-1
-            if (jb == 3) { LTL(35); if (tlog && threadIdx.x == 0) tlog[37] = clock64(); }
+        if (wave < NF3) {
+            // ---- F: the diagonal block alone.  lanes 0-15: its rows; lanes 16-31: identity rows, which leave the loop as D^-1.
+            // (PG_LEAF3_NF = 2..4: waves 1 .. NF3-1 run the SAME instructions on the same data and store nothing -- an experiment on
+            // whether company on the other SIMDs shares the instruction fetch of this 9 KB of straight-line code: it does not,
+            // the factor takes 5100-5400 clocks either way; default 1)
             const int first_bad = leaf3_factor_diag<T>((typename LdsPtr<T>::type)(S + c0 * LD + c0), (typename LdsPtr<T>::type)(Dinv + jb * 16 * DLD),
-                                                       lane);
-            if (jb == 3) { __builtin_amdgcn_s_waitcnt(0xc07f); LTL(36); if (tlog && threadIdx.x == 0) tlog[38] = clock64(); }
-            if (first_bad < 16 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
+                                                       lane, wave == 0);
+            if (wave == 0 && first_bad < 16 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
         }
         __syncthreads();                                               // B: D and D^-1 of this step are published
         LTL(17 + 2 * jb);
@@ -768,13 +771,13 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(r0 + fr) * LD + c0 + Mfma<T>::row(lane, r)] = x0[r];
             }
-        } else {
+        } else if (wave >= NF3) {
             // ---- beside the next step's factor: the rest of this step's trailing update (tiles (ti, tj), 1 <= tj <= ti), block row
             // jb of the inverse (its D^-1 exists since B), and -- in the last such slot -- the sums of the inverse's last block row
             const int nrest = nt * (nt - 1) / 2;
             const int nx = want_inv ? jb : 0;
             const bool last = want_inv && jb == NB / 16 - 2;           // after it only the last diagonal block is factored
-            for (int w = wave - 1; w < nrest + nx + (last ? 1 : 0); w += NWV - 1) {
+            for (int w = wave - NF3; w < nrest + nx + (last ? 1 : 0); w += NWV - NF3) {
                 if (last && w == nrest + nx) {
                     inv_tile_sum<T>(S, Dinv, jb + 1, jb, lane);        // q = 6: L[7][6] Dinv[6]
                     continue;
@@ -872,7 +875,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
 // the pivot loop two scalar registers for its broadcasts.
 template <typename T, bool WT>
 __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
-                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog) {
+                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int nf3) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
     }
     __syncthreads();
     if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
-    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog);
+    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog, nf3);
     if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -899,9 +902,9 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
 }
 template <typename T>
 __global__ __launch_bounds__(NTH) void pg_leaf3_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi, int* __restrict__ info,
-                                                       int col0, long eA, long eInv) {
+                                                       int col0, long eA, long eInv, int nf3) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf3_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0);
+    leaf3_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0, nullptr, nf3);
 }
 
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
@@ -932,8 +935,9 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
                            ((getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3"))) ? 0 : 64);           // third form (default); PG_LEAF3=0: second
     long long* tl = getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr;
     if (abl & 64) {
-        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl);
-        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl);
+        static const int nf3 = getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1;
+        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3);
+        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3);
         PG_CHECK(hipGetLastError());
         return 0;
     }
@@ -965,7 +969,8 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
         attr_done = true;
     }
     if ((ablate & 64) && form != 1 && !(ablate & 15)) {      // third form (no ablation switches)
-        hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv);
+        static const int nf3 = getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1;
+        hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
         PG_CHECK(hipGetLastError());
         return 0;
     }

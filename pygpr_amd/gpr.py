@@ -141,6 +141,7 @@ class Exact_GP(GPR):
         self._data = None
         self._data_key = None
         self._bat = None
+        self._pbuf = None
         self._x_all = self._y_all = None
         self.need_upd: bool = True
         # eager_inverse: form L^-1 inside update() (fused with the Cholesky) and take alpha = L^-T (L^-1 y) from two
@@ -162,6 +163,7 @@ class Exact_GP(GPR):
     def _data_changed(self) -> None:
         self._experts = None
         self._data = None
+        self._pbuf = None
         self.need_upd = True
 
     def _device_data(self):
@@ -328,11 +330,16 @@ class Exact_GP(GPR):
             xq = xpd[s: s + _CHUNK]
             mc = xq.shape[0]
             m_pad = pad_to(mc)
-            kt = ops.empty(m_pad, e.n_pad, dtype=self.dtype)   # K* test-point-major: k(xp, x) (the kernels are symmetric)
+            # K* (test-point-major: k(xp, x); the kernels are symmetric) and the product's scratch are kept per model and shape: all
+            # experts of a model and all chunks of a call run one after the other on the stream, so ONE set serves them (round 2
+            # allocated 604 MB per expert per batch at config 4 through torch's caching allocator)
+            key = (m_pad, e.n_pad, want == "diag")
+            if self._pbuf is None or self._pbuf[0] != key:
+                self._pbuf = (key, ops.empty(m_pad, e.n_pad, dtype=self.dtype), ops.empty((e.n_pad // 64) * m_pad, dtype=self.dtype))
+            kt, work = self._pbuf[1], self._pbuf[2]
             ops.kernel_build(spec, e.hp, xq, e.x, kt)
             mu = ops.empty(m_pad, dtype=self.dtype)
             vq = ops.empty(m_pad, dtype=self.dtype) if want == "diag" else None
-            work = ops.empty((e.n_pad // 64) * m_pad, dtype=self.dtype)
             ops.predict_mean_q_kt(kt, self._minv(e) if want == "diag" else None, e.alpha, mu, vq,
                                   self._kss_diag(b), work)
             mean[s: s + mc] = mu[:mc]

@@ -46,10 +46,3 @@ for k in range(1, min(nblk - 1, 10)):
     parts.append("finish %.2f, last stores %.2f" % ((L[34] - prev) / 100, (L[2] - L[34]) / 100))
     print("%3d " % k + " | ".join(parts))
 
-for k in range(1, 4):
-    L = tl[k]
-    print("%3d third form, step 3, wave 0: barrier B'(2) -> factor start %.2f | factor (call) %.2f | -> barrier B(3) %.2f | shader clocks during the factor %d -> %.2f GHz" % (k, (L[35] - L[18 + 2 * 2]) / 100, (L[36] - L[35]) / 100, (L[17 + 2 * 3] - L[36]) / 100, L[38] - L[37], (L[38] - L[37]) / ((L[36] - L[35]) * 10.0)), "| the same call again at once: %d shader clocks" % (L[39] - L[38]))
-for k in range(0):
-    L = tl[k]
-    print("%3d step 3 of the leaf, wave 0: previous barrier -> phase start %.2f | LDS reads %.2f | 16-column loop %.2f | LDS writes %.2f | barrier wait %.2f" % (
-        k, (L[35] - L[18 + 2 * 2]) / 100, (L[36] - L[35]) / 100, (L[37] - L[36]) / 100, (L[38] - L[37]) / 100, (L[17 + 2 * 3] - L[38]) / 100))
