@@ -166,12 +166,15 @@ __device__ __forceinline__ void cs_mm(typename Mfma<T>::acc_t (&acc)[RG], const 
 // lands.  lower_b: B[n][k] = 0 for k > n.
 template <typename T>
 __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T* Xl, const T* __restrict__ Bg, long ldb, bool lower_b,
-                                           T* Bs) {
+                                           T* Bs, int c_lo = 0, int c_hi = NB / CS_KC, int n_lo = 0, int n_hi = NB) {
+    // K chunks [c_lo, c_hi) of 32 columns, rows [n_lo, n_hi) of B (= the output columns of the waves 16 cg in [n_lo, n_hi)): the
+    // two-phase hand-over runs this twice per product, once on the part of the operand that exists early
     constexpr int VE = 16 / sizeof(T);
     constexpr int VPR = CS_KC / VE, NVB = NB * VPR, UB = (NVB + CS_NTH - 1) / CS_NTH, NCH = NB / CS_KC;
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, (int)((127 * ldb + NB) * sizeof(T)), 0x00020000);
     const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const bool mine = 16 * cg >= n_lo && 16 * cg < n_hi;          // wave-uniform: this wave's output tile takes part
     vec_t vb[NCH][UB];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -179,7 +182,7 @@ __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T
         for (int u = 0; u < UB; ++u) {
             const int v = tid + u * CS_NTH, row = v / VPR;
             // a lower-triangular B has nothing in chunk c for the rows above it
-            if (v < NVB && !(lower_b && row + 1 <= c * CS_KC))
+            if (v < NVB && c >= c_lo && c < c_hi && row >= n_lo && row < n_hi && !(lower_b && row + 1 <= c * CS_KC))
                 vb[c][u] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(
                                                          rB, (int)(((long)row * ldb + c * CS_KC + (v % VPR) * VE) * sizeof(T)), 0, 16));
             else
@@ -188,6 +191,7 @@ __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T
         }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        if (c < c_lo || c >= c_hi) continue;                      // workgroup-uniform
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -199,7 +203,7 @@ __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T
             }
         }
         __syncthreads();
-        if (lower_b && c * CS_KC > 16 * cg + 15) continue;        // wave-uniform
+        if (!mine || (lower_b && c * CS_KC > 16 * cg + 15)) continue;        // wave-uniform
 #pragma unroll
         for (int ks = 0; ks < CS_KC / 4; ++ks)
             acc = Mfma<T>::run(Xl[fr * CS_XLD + c * CS_KC + 4 * ks + fk], Bs[(16 * cg + fr) * CS_CLD + 4 * ks + fk], acc);
@@ -209,7 +213,8 @@ __device__ __forceinline__ void cs_mm_k128(typename Mfma<T>::acc_t& acc, const T
 template <typename T, int RG>
 __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, long lda, int row0, int o0, int k0, bool has_next,
                                              bool crit, const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next, int ncrit,
-                                             const CsWait& tmo, int* info, int direct, long long* tlog) {
+                                             const CsWait& tmo, int* info, int direct, long long* tlog, int* early_k = nullptr,
+                                             int* browe_k = nullptr) {
     constexpr int ROWS = 16 * RG, NJ = RG, WC = 16 * NJ;
 #define TL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     constexpr int VE = 16 / sizeof(T);
@@ -252,6 +257,65 @@ __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[j][r] = (T)0;
     TL(4);
+    // Two-phase hand-over (the eight workgroups the next leaf waits for).  The third leaf form raises *early_k once columns 0..63
+    // of L_kk and rows 0..63 of its inverse are in memory -- three of its eight steps and its tail before *done_k.  With
+    //     X1 = A1 inv11^T,   W = A2 - X1 L21^T,   X2 = W inv22^T          (A = [A1 A2], 64 columns each)
+    // X1, its exchange, W and X1's share of the update of column k+1 run WHILE THE LEAF DOES; behind *done_k are left a 64-deep
+    // solve and a 64-deep update: half the K chunks (each a barrier pair) of the single-phase form on the path to the next leaf.
+    const bool two_phase = RG == 1 && direct && early_k != nullptr && has_next;
+    if (two_phase) {
+        constexpr int HC = NB / 2 / CS_KC, NC = NB / CS_KC;          // K chunks: of a half (2), of the whole (4)
+        T* Xn = Bs + NB * CS_CLD;                                    // [16][CS_XLD] the solved rows (the 32-row workgroups' share of LDS is there)
+        const T* Akk = A + (long)k0 * lda + k0;
+        cs_wg_wait_wt(early_k, 1, tmo, info);
+        cs_mm_k128<T>(t[0], Xl, inv, NB, true, Bs, 0, HC, 0, NB / 2);            // X1 (waves 0..3)
+        if (cg < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = Mfma<T>::row(lane, r), cc = 16 * cg + fr;
+                Xn[rr * CS_XLD + cc] = t[0][r];
+                st_wt<T>(Arow + (long)rr * lda + k0 + cc, t[0][r]);
+            }
+        }
+        cs_wg_signal(browe_k);                                       // (its barrier also orders the Xn stores)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[0][r] = (T)0;
+        cs_mm_k128<T>(t[0], Xn, Akk, lda, false, Bs, 0, HC, NB / 2, NB);         // X1 L21^T (waves 4..7)
+        if (cg >= 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xl[Mfma<T>::row(lane, r) * CS_XLD + 16 * cg + fr] -= t[0][r];      // W over A2
+        }
+        cs_wg_wait_wt(browe_k, ncrit, tmo, info);
+        cs_mm_k128<T>(acc[0], Xn, Brow + k0, lda, false, Bs, 0, HC, 0, NB);      // acc += X1 X1[block row k+1]^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[0][r] = (T)0;
+        cs_wg_wait_wt(done_k, 1, tmo, info);
+        TL(5);
+        cs_mm_k128<T>(t[0], Xl, inv, NB, true, Bs, HC, NC, NB / 2, NB);          // X2 = W inv22^T (waves 4..7)
+        TL(6);
+        if (cg >= 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = Mfma<T>::row(lane, r), cc = 16 * cg + fr;
+                Xn[rr * CS_XLD + cc] = t[0][r];
+                st_wt<T>(Arow + (long)rr * lda + k0 + cc, t[0][r]);
+            }
+        }
+        cs_wg_signal(brow_k);
+        TL(7);
+        cs_wg_wait_wt(brow_k, ncrit, tmo, info);
+        TL(8);
+        cs_mm_k128<T>(acc[0], Xn, Brow + k0, lda, false, Bs, HC, NC, 0, NB);     // acc += X2 X2[block row k+1]^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T* g = Arow + (long)Mfma<T>::row(lane, r) * lda + k0 + NB + 16 * cg + fr;
+            st_wt<T>(g, cin[0][r] - acc[0][r]);
+        }
+        TL(9);
+        cs_wg_signal(diag_next);
+        TL(10);
+        return;
+    }
     if (RG == 1 && direct) {
         cs_wg_wait_wt(done_k, 1, tmo, info);
         TL(5);
@@ -307,12 +371,13 @@ __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, 
 template <typename T>
 __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
                                                                const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
-                                                               CsWait tmo, int* info, int direct, long long* tlog) {
+                                                               CsWait tmo, int* info, int direct, long long* tlog, int* early_k,
+                                                               int* browe_k) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int w = blockIdx.x;
     if (w < CS_NCRIT)
         cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 16 * w, o0, k0, has_next != 0, true, inv, done_k, brow_k, diag_next, CS_NCRIT,
-                           tmo, info, direct, w == 0 ? tlog : nullptr);
+                           tmo, info, direct, w == 0 ? tlog : nullptr, early_k, browe_k);
     else
         cs_rows_body<T, 2>(smem_raw, A, lda, k0 + 2 * NB + 32 * (w - CS_NCRIT), o0, k0, has_next != 0, false, inv, done_k, brow_k,
                            diag_next, CS_NCRIT, tmo, info, direct, nullptr);
@@ -322,7 +387,7 @@ __global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(fla
 
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, const CsWait& tmo, int* info) {
+               int* diag_next, const CsWait& tmo, int* info, int* early_k, int* browe_k) {
     const int m = n - k0 - NB;
     if (m <= 0 || m % NB) { pg_set_error("pg_rowstep: %d rows below the tile", m); return -2; }
     const size_t lds = (size_t)(32 * CS_XLD + 32 * CS_CLD + NB * CS_CLD) * sizeof(T);
@@ -335,12 +400,13 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
     static const int direct = getenv("PG_CS_K128") ? atoi(getenv("PG_CS_K128")) : 1;
     hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
-                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr);
+                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr, direct ? early_k : nullptr,
+                       browe_k);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*);
-template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*);
+template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*, int*, int*);
+template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*, int*, int*);
 
 int pg_flagset(hipStream_t st, int* flag, int value) {
     hipLaunchKernelGGL(pg_flagset_kernel, dim3(1), dim3(1), 0, st, flag, value);

@@ -669,20 +669,25 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
 
 template <typename T, bool WT>
 __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
-                                           int* __restrict__ info, int col0, long long* tlog = nullptr, int nf3 = 1) {
+                                           int* __restrict__ info, int col0, long long* tlog = nullptr, int nf3 = 1,
+                                           int* early = nullptr) {
 #define LTL(i) do { if (tlog && threadIdx.x == 0) tlog[i] = wall_clock64(); } while (0)
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((127 * lda + 128) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(inv, 0, inv ? (int)((127 * ldi + 128) * sizeof(T)) : 0, 0x00020000);
     T* S = reinterpret_cast<T*>(smem_raw);
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
     int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
+    int* ecnt = &fail + 1;                                  // waves that have drained their early stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T pair_t __attribute__((ext_vector_type(2)));
 
-    if (*info != 0) return;
-    if (tid == 0) fail = 0;
+    if (*info != 0) {
+        if (early && tid == 0) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody may wait for it
+        return;
+    }
+    if (tid == 0) { fail = 0; *ecnt = 0; }
     {   // lower triangle -> LDS, two columns per thread, 64 pairs per row; all loads are issued before the first use
         constexpr int NLD = (NB * NB / 2 + NTH - 1) / NTH;
         pair_t v[NLD];
@@ -705,6 +710,37 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     __syncthreads();
     LTL(16);
     const bool want_inv = inv != nullptr;
+    // 16 columns of L (all 128 rows: zeros above the diagonal) / rows of the inverse -> global, by the threads t0, t0 + nth, ...
+    auto store_l_panel = [&](int jbp, int t0, int nth) {
+        const int cc0 = 16 * jbp;
+        for (int idx = t0; idx < NB * 8; idx += nth) {
+            const int i = idx >> 3, k = cc0 + (idx & 7) * 2;
+            pair_t v = {(T)0, (T)0};
+            if (i >= cc0) v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+            if (k > i) v[0] = (T)0;
+            if (k + 1 > i) v[1] = (T)0;
+            if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+            else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+        }
+    };
+    auto store_inv_rows = [&](int row_lo, int row_hi, int t0, int nth) {
+        for (int idx = row_lo * 64 + t0; idx < row_hi * 64; idx += nth) {
+            const int i = idx >> 6, k = (idx & 63) * 2;
+            const int pb = i >> 4, qb = k >> 4, ii = i & 15;
+            pair_t v = {(T)0, (T)0};
+            if (qb == pb) {
+                const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
+                v[0] = (k <= i) ? Dv[0] : (T)0;
+                v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
+            } else if (qb < pb) {
+                const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
+                v[0] = Xt[0];
+                v[1] = Xt[1];
+            }
+            if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
+            else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+        }
+    };
     const int NF3 = nf3;                                    // waves that run the factor's instructions (wave 0 for real)
     acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
     for (int jb = 0; jb < NB / 16; ++jb) {
@@ -794,39 +830,37 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
                     if (last) inv_tile_sum<T>(S, Dinv, jb + 1, w - nrest, lane);
                 }
             }
+            // ---- still beside the factor (these waves idle for most of it): what the PREVIOUS step made final goes out -- its
+            // sixteen columns of L and block row jb - 1 of the inverse -- so that the tail stores two panels and two block rows
+            // instead of everything.  After step 4's slot the inverse's first four block rows are out: each storing wave drains,
+            // counts itself in LDS, and the last one raises *early -- the rows of block row k+1 start their solve against
+            // those 64 rows while the leaf still has three steps and its tail to run (chainstep.hip).
+            if (jb >= 1) {
+                const int t0 = tid - 64 * NF3, nth = NTH - 64 * NF3;
+                store_l_panel(jb - 1, t0, nth);
+                if (want_inv) store_inv_rows(16 * (jb - 1), 16 * jb, t0, nth);
+                if (early && jb == 4) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+                        const int before = atomicAdd(ecnt, 1);                     // LDS
+                        if (before == NWV - NF3 - 1) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
         }
     }
-    // the loop ends behind B of the last step: L is complete; of the inverse only the last block row's final products are missing
+    // the loop ends behind B of the last step: L is complete; of the inverse only the last block row's final products are missing.
+    // Panels 0-5 of L and block rows 0-5 of the inverse went out while the loop ran.
     if (want_inv) {
         for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);
     }
-    for (int idx = tid; idx < NB * NB / 2; idx += NTH) {
-        const int i = idx >> 6, k = (idx & 63) * 2;
-        pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
-        if (k > i) v[0] = (T)0;
-        if (k + 1 > i) v[1] = (T)0;
-        if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
-        else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
-    }
+    store_l_panel(6, tid, NTH);
+    store_l_panel(7, tid, NTH);
     if (!want_inv) return;
+    store_inv_rows(96, 112, tid, NTH);
     __syncthreads();
     LTL(34);
-    for (int idx = tid; idx < NB * 64; idx += NTH) {
-        const int i = idx >> 6, k = (idx & 63) * 2;
-        const int pb = i >> 4, qb = k >> 4, ii = i & 15;
-        pair_t v = {(T)0, (T)0};
-        if (qb == pb) {
-            const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + (k & 15);
-            v[0] = (k <= i) ? Dv[0] : (T)0;
-            v[1] = (k + 1 <= i) ? Dv[1] : (T)0;
-        } else if (qb < pb) {
-            const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + (k & 15);
-            v[0] = Xt[0];
-            v[1] = Xt[1];
-        }
-        if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
-        else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
-    }
+    store_inv_rows(112, 128, tid, NTH);
 #undef LTL
 }
 
@@ -875,7 +909,8 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
 // the pivot loop two scalar registers for its broadcasts.
 template <typename T, bool WT>
 __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
-                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int nf3) {
+                                                        int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int nf3,
+                                                        int* early) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
@@ -887,7 +922,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
     }
     __syncthreads();
     if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
-    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog, nf3);
+    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog, nf3, WT ? early : nullptr);
     if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -897,6 +932,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (early) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every path: nobody waits for ever
         __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -907,8 +943,12 @@ __global__ __launch_bounds__(NTH) void pg_leaf3_kernel(T* __restrict__ A, long l
     leaf3_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0, nullptr, nf3);
 }
 
+bool pg_leaf_has_early() {   // the coupled leaf raises its early flag before its done flag (third form, write-through hand-off)
+    static const bool v = !(getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3"))) && !(getenv("PG_CS_LEAF_WT") && !atoi(getenv("PG_CS_LEAF_WT")));
+    return v;
+}
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
-                                       const CsWait& tmo) {
+                                       const CsWait& tmo, int* early) {
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -936,8 +976,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     long long* tl = getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr;
     if (abl & 64) {
         static const int nf3 = getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1;
-        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3);
-        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3);
+        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
+        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         PG_CHECK(hipGetLastError());
         return 0;
     }
@@ -948,8 +988,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&);
-template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&);
+template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&, int*);
+template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&, int*);
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate, int nexp, long eA,
                                   long eInv) {

@@ -569,11 +569,16 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     int* f_diag = reinterpret_cast<int*>(flagw);   // [nblk] workgroups that have published tile (b, b)
     int* f_done = f_diag + nblk;                // [nblk] leaf b has stored L_bb and its inverse
     int* f_brow = f_done + nblk;                // [nblk] workgroups that have published X[block row b+1, block column b]
-    int* f_tmo = f_brow + nblk;                 // sticky time-out word
+    int* f_early = f_brow + nblk;               // [nblk] leaf b has stored the first 64 rows of its inverse (two-phase hand-over)
+    int* f_browe = f_early + nblk;              // [nblk] workgroups that have published the first 64 columns of X[block row b+1, block column b]
+    int* f_tmo = f_browe + nblk;                // sticky time-out word
     if (o_s < npan) ctx->chain_epoch = ctx->chain_epoch % 1000000 + 1;
     const CsWait cw = {f_tmo, ctx->tmo_dev, ctx->spin_ticks, ctx->chain_epoch};
+    // two-phase hand-over (chainstep.hip): only the third leaf form raises the early flag
+    static const bool two_phase_env = !(getenv("PG_CS_TWO_PHASE") && atoi(getenv("PG_CS_TWO_PHASE")) == 0);
+    const bool two_phase = two_phase_env && pg_leaf_has_early();
     if (o_s < npan) {
-        PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((3 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
+        PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((5 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
     }
     for (int o = 0; o < npan; ++o) {
         const int o0 = pb[o], oend = pb[o + 1];
@@ -590,7 +595,9 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             for (int k0 = o0; k0 < oend; k0 += NB) {
                 const int kb = k0 / NB;
                 T* inv = invD + (long)kb * NB * NB;
-                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw))) return rc;
+                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw,
+                                          two_phase ? f_early + kb : nullptr)))
+                    return rc;
                 if (n - k0 - NB <= 0) break;
                 const int c = k0 + NB;                       // the block column this step brings up to date
                 const int oc = c < oend ? o : o + 1;         // its panel
@@ -603,7 +610,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
-                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info)))
+                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info,
+                                        two_phase ? f_early + kb : nullptr, f_browe + kb)))
                     return rc;
             }
         }

@@ -20,7 +20,7 @@ for _ in range(3):
     torch.cuda.synchronize()
 nblk = n // 128
 base = n * 128                              # doubles: start of the flag words (right behind the diagonal-block inverses)
-tmo_off_bytes = base * 8 + 3 * nblk * 4
+tmo_off_bytes = base * 8 + 5 * nblk * 4
 tl = invd.view(torch.int64)[(tmo_off_bytes // 8) + 512: (tmo_off_bytes // 8) + 512 + 48 * nblk].cpu().numpy().reshape(nblk, 48)
 # wall_clock64: 100 MHz
 t0 = tl[0, 0]
