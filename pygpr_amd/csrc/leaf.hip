@@ -667,6 +667,10 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
     return first_bad;
 }
 
+// (Round 3 also tried the chain as a LOOP -- registers rotate instead of the code: row[k-1] = row[k] - row[0] w_k, the pivot always in
+// row[0], its column a run-time lane of v_readlane; two loops of eight pivots, 0.9 KB of code instead of 9 KB, bit-identical factor.
+// A step took 4.6 us instead of 2.9 (n = 4096: 1.54 -> 1.85 ms): every iteration pays all fifteen broadcasts, and the wave issues
+// about one instruction per 7 clocks whether the code is short or long.  Removed again; DESIGN.md has the numbers.)
 template <typename T, bool WT>
 __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                            int* __restrict__ info, int col0, long long* tlog = nullptr, int nf3 = 1,
@@ -741,7 +745,13 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
         }
     };
-    const int NF3 = nf3;                                    // waves that run the factor's instructions (wave 0 for real)
+    const int NF3 = nf3 & 15;                               // waves that run the factor's instructions (wave 0 for real)
+    // bit 4 (default; PG_LEAF3_ALONE=0 clears it): the waves that share wave 0's SIMD (4, 8: waves go round the four SIMDs) sit out the
+    // slot beside the factor: their MFMA / LDS work took issue cycles from the pivot chain (a step 2.9 -> 2.2-2.7 us; n = 4096
+    // 1.535 -> 1.475 ms, the nine remaining workers finish within the factor's time except in the last slot)
+    const bool alone = (nf3 & 16) != 0;
+    const bool worker = alone ? (wave & 3) != 0 : wave >= NF3;
+    const int widx = alone ? (wave >> 2) * 3 + (wave & 3) - 1 : wave - NF3, nwork = alone ? (NWV / 4) * 3 : NWV - NF3;
     acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
@@ -807,13 +817,13 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(r0 + fr) * LD + c0 + Mfma<T>::row(lane, r)] = x0[r];
             }
-        } else if (wave >= NF3) {
+        } else if (worker) {
             // ---- beside the next step's factor: the rest of this step's trailing update (tiles (ti, tj), 1 <= tj <= ti), block row
             // jb of the inverse (its D^-1 exists since B), and -- in the last such slot -- the sums of the inverse's last block row
             const int nrest = nt * (nt - 1) / 2;
             const int nx = want_inv ? jb : 0;
             const bool last = want_inv && jb == NB / 16 - 2;           // after it only the last diagonal block is factored
-            for (int w = wave - NF3; w < nrest + nx + (last ? 1 : 0); w += NWV - NF3) {
+            for (int w = widx; w < nrest + nx + (last ? 1 : 0); w += nwork) {
                 if (last && w == nrest + nx) {
                     inv_tile_sum<T>(S, Dinv, jb + 1, jb, lane);        // q = 6: L[7][6] Dinv[6]
                     continue;
@@ -836,14 +846,14 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             // counts itself in LDS, and the last one raises *early -- the rows of block row k+1 start their solve against
             // those 64 rows while the leaf still has three steps and its tail to run (chainstep.hip).
             if (jb >= 1) {
-                const int t0 = tid - 64 * NF3, nth = NTH - 64 * NF3;
+                const int t0 = 64 * widx + lane, nth = 64 * nwork;
                 store_l_panel(jb - 1, t0, nth);
                 if (want_inv) store_inv_rows(16 * (jb - 1), 16 * jb, t0, nth);
                 if (early && jb == 4) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) {
                         const int before = atomicAdd(ecnt, 1);                     // LDS
-                        if (before == NWV - NF3 - 1) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (before == nwork - 1) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -975,7 +985,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
                            ((getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3"))) ? 0 : 64);           // third form (default); PG_LEAF3=0: second
     long long* tl = getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr;
     if (abl & 64) {
-        static const int nf3 = getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1;
+        static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
+                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16);
         if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         PG_CHECK(hipGetLastError());
@@ -1009,7 +1020,8 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
         attr_done = true;
     }
     if ((ablate & 64) && form != 1 && !(ablate & 15)) {      // third form (no ablation switches)
-        static const int nf3 = getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1;
+        static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
+                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16);
         hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
         PG_CHECK(hipGetLastError());
         return 0;

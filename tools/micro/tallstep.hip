@@ -308,6 +308,8 @@ __global__ void chain_probe(double* out, long long* t) {
     if (threadIdx.x == 0) { t[0] = (t1 - t0) / 16; t[1] = (t2 - t1) / 16; t[2] = (t3 - t2) / 16; }
 }
 
+__global__ void noise_kernel(int* p) { if (p && threadIdx.x == 1000) *p = 1; }
+
 int main() {
     std::vector<double> h(64 * 16), ref(64 * 16);
     srand(1);
@@ -335,6 +337,26 @@ int main() {
       double err = 0; for (int l = 0; l < 64; ++l) for (int c = 0; c < 16; ++c) if (l >= 16 || c <= l) err = fmax(err, fabs(o[l * 16 + c] - ref[l * 16 + c])); \
       printf("variant %d: %lld clock64 ticks, %lld ns per 16-column step (%.0f ns per column), FIRST step of the launch (cold instruction cache) %lld ticks, max abs err vs long-double Cholesky %.2e\n", V, ht[0], ht[1], ht[1] / 16.0, ht[2], err); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
+    // Does a DISPATCH elsewhere on the GPU cost a running wave its instruction cache?  The same hot loop, 40000 repetitions, while the
+    // host launches empty kernels: (a) none, (b) back to back on one other stream, (c) on two streams that wait for each other's events
+    // (every launch behind a barrier packet: the form the factorisation's look-ahead produces).
+    {
+        hipStream_t sa, sb, sm; hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+        hipStreamCreateWithFlags(&sm, hipStreamNonBlocking);
+        hipEvent_t ea, eb; hipEventCreateWithFlags(&ea, hipEventDisableTiming); hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+        for (int mode = 0; mode < 3; ++mode) {
+            bench<3><<<1, 256, 0, sm>>>(din, dout, dt, 40000);
+            int launched = 0;
+            while (hipStreamQuery(sm) == hipErrorNotReady && mode > 0) {
+                if (mode == 1) { noise_kernel<<<1, 64, 0, sa>>>(nullptr); ++launched; }
+                else { noise_kernel<<<1, 64, 0, sa>>>(nullptr); hipEventRecord(ea, sa); hipStreamWaitEvent(sb, ea, 0);
+                       noise_kernel<<<1, 64, 0, sb>>>(nullptr); hipEventRecord(eb, sb); hipStreamWaitEvent(sa, eb, 0); launched += 2; }
+            }
+            hipDeviceSynchronize(); hipMemcpy(ht, dt, 24, hipMemcpyDeviceToHost);
+            printf("dispatch noise mode %d (%s): %lld clock64 ticks per step, %d kernels launched meanwhile\n", mode,
+                   mode == 0 ? "quiet" : (mode == 1 ? "one stream, back to back" : "two streams, event ping-pong"), ht[0], launched);
+        }
+    }
 #define PRUN(V, W)                                                                                                  \
     { phase_bench<V, W><<<1, 768>>>(din, dout, dt, 400); hipDeviceSynchronize(); hipMemcpy(ht, dt, 32, hipMemcpyDeviceToHost); \
       printf("phase V%d W%d: LDS reads %lld ns, 16-column loop %lld ns, LDS writes + drain %lld ns, barrier %lld ns\n", V, W, ht[0], ht[1], ht[2], ht[3]); }
