@@ -50,6 +50,36 @@ __device__ __forceinline__ double pg_exp(double x) {
 }
 __device__ __forceinline__ float pg_exp(float x) { return expf(x); }
 
+// The covariance build's own exponential (round 3): the build is bound by fp64 VALU issue, and the degree-13 chain above is half of an
+// element's instructions.  Here x = (32 e + j) ln2 / 32 + r with |r| <= ln2 / 64: 2^(j/32) comes from a 32-entry table in LDS
+// (32 doubles cover the 64 banks once: no conflicts between distinct entries), exp(r) from the Taylor polynomial to degree 6
+// (truncation r^7 / 7! < 3.5e-18), 2^e from v_ldexp_f64: 13 fp64 operations instead of 21, <= 2 ulp.  `tab` may carry a factor
+// (the component's sigma^2) -- the product costs nothing then.
+__device__ const double pg_exp2_32[32] = {
+    1.00000000000000000e+00, 1.02189714865411663e+00, 1.04427378242741375e+00, 1.06714040067682370e+00,
+    1.09050773266525769e+00, 1.11438674259589243e+00, 1.13878863475669156e+00, 1.16372485877757748e+00,
+    1.18920711500272103e+00, 1.21524735998046896e+00, 1.24185781207348400e+00, 1.26905095719173322e+00,
+    1.29683955465100964e+00, 1.32523664315974132e+00, 1.35425554693689265e+00, 1.38390988196383202e+00,
+    1.41421356237309515e+00, 1.44518080697704665e+00, 1.47682614593949935e+00, 1.50916442759342284e+00,
+    1.54221082540794074e+00, 1.57598084510788650e+00, 1.61049033194925428e+00, 1.64575547815396495e+00,
+    1.68179283050742900e+00, 1.71861929812247793e+00, 1.75625216037329945e+00, 1.79470907500310717e+00,
+    1.83400808640934243e+00, 1.87416763411029996e+00, 1.91520656139714740e+00, 1.95714412417540018e+00};
+__device__ __forceinline__ double pg_exp_tab(double x, const double* tab) {
+    x = (x < -800.0) ? -800.0 : x;      // (a NaN argument stays NaN)
+    const double kf = __builtin_rint(x * 4.61662413084468283841e+01);              // 32 / ln2
+    double r = __builtin_fma(-kf, 2.16608493865351192653e-02, x);                   // ln2 / 32, upper 32 bits: kf * hi is exact
+    r = __builtin_fma(-kf, 5.96317165397058656257e-12, r);
+    const int k = (int)kf;
+    double p = 1.3888888888888889e-03;                  // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332e-03);    // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);    // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);    // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p * tab[k & 31], k >> 5);
+}
+
 template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, T sqd) {
     if (kind == PG_KIND_RBF) return sig2 * pg_exp(-sqd);
     if (kind == PG_KIND_SQDIST) return sqd;    // Squared_exponential.distance (covar.py:102-127): the scaled squared distance itself
@@ -60,13 +90,13 @@ template <typename T> __device__ __forceinline__ T comp_value(int kind, T sig2, 
 
 template <typename T>
 __device__ __forceinline__ void stage_points(T* dst, const T* __restrict__ X, long ldx, int npts, int p0, int d, int tid,
-                                             const double* __restrict__ scale = nullptr) {
+                                             const double* __restrict__ scale = nullptr, double mul = 1.0) {
     // dst[k][64] <- X[p0 + p][k] (* scale[k]: coordinates pre-multiplied by the inverse length scales); points beyond npts read as zero
     for (int idx = tid; idx < KT * d; idx += 256) {
         const int p = idx / d, k = idx % d;
         const int gp = p0 + p;
         T v = (gp < npts) ? X[(long)gp * ldx + k] : (T)0;
-        if (scale) v = (T)((double)v * scale[k]);
+        if (scale) v = (T)((double)v * scale[k] * mul);      // (mul = 2: exact)
         dst[k * KT + p] = v;
     }
 }
@@ -112,10 +142,14 @@ __device__ __forceinline__ void kb_strip_of(int b, int symmetric, int c0, int c1
 //   CHECKED: the tile touches the diagonal, the padding or an accumulate pass -- per-element fix-ups; interior tiles skip them
 // The kernel is bound by fp64 VALU issue, not by HBM, at d = 8 (about 250 VALU cycles per 64 elements against the 120 their
 // stores take at 5.3 TB/s): both switches only remove instructions.
-template <typename T, bool PRESC, bool CHECKED, bool MIRROR>
+//   FAST   : (fp64, PRESC, the component is the squared exponential) the reference's own form of the squared distance,
+//            |x|^2 + |x'|^2 - 2 x.x' (covar.py:102-127, there a matmul): one FMA per coordinate instead of a subtraction and an
+//            FMA.  The rows are staged times two, -|x|^2 per point waits in LDS (nrm_r, nrm_c), so the accumulator STARTS at
+//            -|x|^2 - |x'|^2 and ends as the exponential's argument; pg_exp_tab with sigma^2 folded into its table.
+template <typename T, bool PRESC, bool CHECKED, bool MIRROR, bool FAST = false>
 __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, const T* xc, const T* l2, const T* sg2, T* tt, int d,
                                         int tr, int tc, int nr, int nc, int symmetric, int accumulate, T* __restrict__ K, long ldk,
-                                        int tid) {
+                                        int tid, const T* nrm_r = nullptr, const T* nrm_c = nullptr, const double* tab = nullptr) {
     constexpr int VE = VecOf<T>::N, NVC = 4 / VE;   // vectors per row of the micro-tile
     typedef typename VecOf<T>::type vec_t;
     const int tx = tid & 15, ty = tid >> 4;
@@ -124,7 +158,43 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[r][c] = (T)0;
-    for (int cp = 0; cp < spec.ncomp; ++cp) {
+    if (FAST) {
+        T arg[4][4];
+        {
+            T na[4], nb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) na[r] = nrm_r[ty * 4 + r];
+#pragma unroll
+            for (int v = 0; v < NVC; ++v)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) nb[v * VE + e] = nrm_c[v * (16 * VE) + tx * VE + e];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) arg[r][c] = na[r] + nb[c];
+        }
+#pragma unroll 2
+        for (int k = 0; k < d; ++k) {
+            T a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = xr[k * KT + ty * 4 + r];
+#pragma unroll
+            for (int v = 0; v < NVC; ++v) {
+                const vec_t bv = *reinterpret_cast<const vec_t*>(xc + k * KT + v * (16 * VE) + tx * VE);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) b[v * VE + e] = bv[e];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) arg[r][c] += a[r] * b[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[r][c] = (T)pg_exp_tab((double)arg[r][c], tab);
+    }
+    for (int cp = 0; cp < (FAST ? 0 : spec.ncomp); ++cp) {
         const T* lc = l2 + cp * d;
         T sq[4][4];
 #pragma unroll
@@ -230,7 +300,7 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
 // and the launch are paid once per strip, and the next tile's column points are fetched (global -> registers -> the other LDS
 // buffer) while the current tile is computed.  A tile's time was 7 us of staging latency, synchronisation and drain around 1 us of
 // arithmetic with four workgroups per CU to hide it (rocprof: 2.55 TB/s on the lower-only build); the strip hides it behind work.
-template <typename T, bool MIRROR, int NPF>
+template <typename T, bool MIRROR, int NPF, bool FASTK = false>
 __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                         const T* __restrict__ Xr, long ldr, int nr,
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
@@ -247,6 +317,9 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
     T* l2 = xc + 2 * KT * d;        // [ncomp][d] squared inverse length scales
     T* sg2 = l2 + PG_MAX_COMP * d;  // [PG_MAX_COMP] sigma^2, then the diagonal term
     T* tt = sg2 + PG_MAX_COMP + 2;  // MIRROR: [64][TLD] transposed tile
+    T* nrm = tt + (MIRROR ? KT * TLD : 0);                      // fast path: -|x|^2 of the row points [64], of the column points [2][64]
+    double* tab = reinterpret_cast<double*>(nrm + 3 * KT);      // fast path: sigma^2 2^(j/32) [32] (fp64 builds only)
+    constexpr bool fast = FASTK;                                // host: one squared-exponential component, fp64, PG_KB_FAST (presc = 2)
     const int tid = threadIdx.x;
     const double* scale = presc ? hp + spec.off[0] + 1 : nullptr;
     // this thread's share of a point tile: elements idx = tid + 256 u < 64 d  ->  point idx / d, coordinate idx % d
@@ -273,7 +346,7 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
             if (pp[u] >= 0) dst[kk[u] * KT + pp[u]] = pf[u];
     };
     load_cols(tcs);
-    stage_points(xr, Xr, ldr, nr, tr * KT, d, tid, scale);
+    stage_points(xr, Xr, ldr, nr, tr * KT, d, tid, scale, fast ? 2.0 : 1.0);
     for (int idx = tid; idx < spec.ncomp * d; idx += 256) {
         const int c = idx / d, k = idx % d;
         const double l = hp[spec.off[c] + 1 + k];
@@ -289,7 +362,28 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
         sg2[PG_MAX_COMP] = (T)dg;
     }
     store_cols(xc);
+    if (fast && tid < 32) {
+        const double sg = hp[spec.off[0]];
+        tab[tid] = sg * sg * pg_exp2_32[tid];
+    }
     __syncthreads();
+    // -|x|^2 per staged point, one thread per point (rows: staged times two, hence the quarter)
+    auto col_norms = [&](const T* pts, T* dst) {
+        if (tid < KT) {
+            T sacc = (T)0;
+            for (int k = 0; k < d; ++k) { const T v = pts[k * KT + tid]; sacc += v * v; }
+            dst[tid] = -sacc;
+        }
+    };
+    if (fast) {
+        if (tid >= KT && tid < 2 * KT) {
+            T sacc = (T)0;
+            for (int k = 0; k < d; ++k) { const T v = xr[k * KT + tid - KT]; sacc += v * v; }
+            nrm[tid - KT] = (T)-0.25 * sacc;
+        }
+        col_norms(xc, nrm + KT);
+        __syncthreads();
+    }
     // workgroup-uniform: every tile of the strip lies strictly below the diagonal (or the build is a cross build) and inside the
     // real points -- the strip then runs the body without per-element fix-ups.  ONE body per workgroup: with both bodies inlined
     // in the tile loop the kernel needed 160 VGPRs (three workgroups per CU instead of four).
@@ -304,16 +398,27 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
             if (t + 1 < ntile) {
                 store_cols(xc + ((t + 1) & 1) * KT * d);
                 __syncthreads();   // publishes the next tile's points; also orders this tile's reads of `tt` before the next one's writes
+                if (fast) {
+                    col_norms(xc + ((t + 1) & 1) * KT * d, nrm + KT + ((t + 1) & 1) * KT);
+                    __syncthreads();
+                }
             }
         }
     };
 #define KB_ARGS(cur, tc) spec, xr, cur, l2, sg2, tt, d, tr, tc, nr, nc, symmetric, accumulate, K, ldk, tid
-    if (presc) {
-        if (interior) walk([&](const T* cur, int tc) { kb_body<T, true, false, MIRROR>(KB_ARGS(cur, tc)); });
-        else walk([&](const T* cur, int tc) { kb_body<T, true, true, MIRROR>(KB_ARGS(cur, tc)); });
+    if constexpr (FASTK) {
+#define KB_FARGS(cur, tc) KB_ARGS(cur, tc), nrm, nrm + KT + (int)((cur - xc) / (KT * d)) * KT, tab
+        if (interior) walk([&](const T* cur, int tc) { kb_body<T, true, false, MIRROR, true>(KB_FARGS(cur, tc)); });
+        else walk([&](const T* cur, int tc) { kb_body<T, true, true, MIRROR, true>(KB_FARGS(cur, tc)); });
+#undef KB_FARGS
     } else {
-        if (interior) walk([&](const T* cur, int tc) { kb_body<T, false, false, MIRROR>(KB_ARGS(cur, tc)); });
-        else walk([&](const T* cur, int tc) { kb_body<T, false, true, MIRROR>(KB_ARGS(cur, tc)); });
+        if (presc) {
+            if (interior) walk([&](const T* cur, int tc) { kb_body<T, true, false, MIRROR>(KB_ARGS(cur, tc)); });
+            else walk([&](const T* cur, int tc) { kb_body<T, true, true, MIRROR>(KB_ARGS(cur, tc)); });
+        } else {
+            if (interior) walk([&](const T* cur, int tc) { kb_body<T, false, false, MIRROR>(KB_ARGS(cur, tc)); });
+            else walk([&](const T* cur, int tc) { kb_body<T, false, true, MIRROR>(KB_ARGS(cur, tc)); });
+        }
     }
 #undef KB_ARGS
 }
@@ -328,10 +433,10 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
         return -2;
     }
     const bool mirror = symmetric && !lower_only;
-    const size_t lds = (size_t)(3 * KT * d + PG_MAX_COMP * d + PG_MAX_COMP + 2 + (mirror ? KT * TLD : 0)) * sizeof(T);
+    const size_t lds = (size_t)(3 * KT * d + PG_MAX_COMP * d + PG_MAX_COMP + 2 + (mirror ? KT * TLD : 0) + 3 * KT) * sizeof(T) + 32 * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {   // large d passes the 64 KB a kernel gets without opting in (134 KB for the mirrored fp64 build at d = 64)
-        const size_t lds_max = (size_t)(3 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD) * sizeof(T);
+        const size_t lds_max = (size_t)(3 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD + 3 * KT) * sizeof(T) + 32 * sizeof(double);
         const void* fns[6] = {reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 2>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 4>),
                               reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 16>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 2>),
                               reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 4>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 16>)};
@@ -360,13 +465,34 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
     // one stationary component (the common Compose([SE, WN])): its inverse length scales go into the staged coordinates.  In fp64
     // (x l) - (x' l) rounds differently from l^2 (x - x')^2 in the last bit; PG_KB_PRESC=0 keeps the unscaled form
     static const int presc_env = getenv("PG_KB_PRESC") ? atoi(getenv("PG_KB_PRESC")) : 1;
-    const int presc = (presc_env && spec.ncomp == 1) ? 1 : 0;
+    // ... and when that component is the squared exponential, fp64 builds take the fast body (kb_body, FAST): presc = 2
+    static const int fast_env = getenv("PG_KB_FAST") ? atoi(getenv("PG_KB_FAST")) : 1;
+    const int presc = (presc_env && spec.ncomp == 1) ? ((fast_env && sizeof(T) == 8 && spec.kind[0] == PG_KIND_RBF && !accumulate) ? 2 : 1) : 0;
     const int npf = d <= 8 ? 2 : (d <= 16 ? 4 : 16);
-#define KB_LAUNCH(M, P)                                                                                                              \
-    hipLaunchKernelGGL((pg_kbuild_kernel<T, M, P>), dim3((unsigned)strips, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, \
+#define KB_LAUNCH(M, P, F)                                                                                                           \
+    hipLaunchKernelGGL((pg_kbuild_kernel<T, M, P, F>), dim3((unsigned)strips, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, \
                        ldc, nc, d, symmetric, accumulate, jitter, K, ldk, c0, c1, presc, S, eX, ehp, eK)
-    if (mirror) { if (npf == 2) KB_LAUNCH(true, 2); else if (npf == 4) KB_LAUNCH(true, 4); else KB_LAUNCH(true, 16); }
-    else { if (npf == 2) KB_LAUNCH(false, 2); else if (npf == 4) KB_LAUNCH(false, 4); else KB_LAUNCH(false, 16); }
+    bool launched = false;
+    if constexpr (sizeof(T) == 8) {
+        if (presc == 2) {
+            static bool fattr = false;
+            if (!fattr) {
+                const size_t lds_max = (size_t)(3 * KT * PG_MAX_DIM + PG_MAX_COMP * PG_MAX_DIM + PG_MAX_COMP + 2 + KT * TLD + 3 * KT) * sizeof(T) + 32 * sizeof(double);
+                const void* fns[6] = {reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 2, true>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 4, true>),
+                                      reinterpret_cast<const void*>(pg_kbuild_kernel<T, true, 16, true>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 2, true>),
+                                      reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 4, true>), reinterpret_cast<const void*>(pg_kbuild_kernel<T, false, 16, true>)};
+                for (const void* f : fns) PG_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                fattr = true;
+            }
+            if (mirror) { if (npf == 2) KB_LAUNCH(true, 2, true); else if (npf == 4) KB_LAUNCH(true, 4, true); else KB_LAUNCH(true, 16, true); }
+            else { if (npf == 2) KB_LAUNCH(false, 2, true); else if (npf == 4) KB_LAUNCH(false, 4, true); else KB_LAUNCH(false, 16, true); }
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (mirror) { if (npf == 2) KB_LAUNCH(true, 2, false); else if (npf == 4) KB_LAUNCH(true, 4, false); else KB_LAUNCH(true, 16, false); }
+        else { if (npf == 2) KB_LAUNCH(false, 2, false); else if (npf == 4) KB_LAUNCH(false, 4, false); else KB_LAUNCH(false, 16, false); }
+    }
 #undef KB_LAUNCH
     PG_CHECK(hipGetLastError());
     return 0;

@@ -630,7 +630,12 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 // fewer than two 64-row workgroups per CU: half the row tile keeps two waves on every SIMD (gemm.h); in the
                 // chain-bound tail the launch's latency is what counts: 32 x 32 tiles with a 64-deep K tile
                 static const int u32rows = getenv("PG_U32_ROWS") ? atoi(getenv("PG_U32_ROWS")) : 8192;
-                const int uv = (p.M <= u32rows && p.K % 64 == 0) ? GEMM_NT_32x32 : (p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64);
+                int uv = (p.M <= u32rows && p.K % 64 == 0) ? GEMM_NT_32x32 : (p.M <= 12288 ? GEMM_NT_32x64 : GEMM_NT_64);
+                // experts together: every launch carries nexp times the tiles, and the panel stream shares the chip with the batch's
+                // trailing update -- throughput per tile counts there, not the launch's latency
+                static const int buv = getenv("PG_BATCH_UV") ? atoi(getenv("PG_BATCH_UV")) : 2;   // 8 x 4096: 0: 9.54, 1: 9.25, 2: 9.04 ms
+                if (nexp > 1 && buv == 1) uv = GEMM_NT_32x64;
+                if (nexp > 1 && buv == 2 && (long)(p.M / 64) * 2 * nexp >= 256) uv = GEMM_NT_64;
                 if ((rc = pg_gemm<T>(ctx, ps, uv, p))) return rc;
             }
             if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0, 0, nexp, eA, eI))) return rc;
