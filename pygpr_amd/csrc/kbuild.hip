@@ -332,18 +332,23 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
         kk[u] = idx < KT * d ? idx % d : 0;
         sc[u] = (scale && pp[u] >= 0) ? scale[kk[u]] : 1.0;
     }
+    // The prefetch must stay a prefetch: the loads are UNCONDITIONAL (clamped address) and nothing touches their result before
+    // store_cols.  Written as `valid ? X[..] * scale : 0` each load sat in its own exec-masked block with `s_waitcnt vmcnt(0)` right
+    // behind it -- two serial load latencies per tile, each also waiting for the previous tile's stores to drain.
     T pf[NPF];
+    bool pok[NPF];
     auto load_cols = [&](int tc) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
             const int gp = tc * KT + pp[u];
-            pf[u] = (pp[u] >= 0 && gp < nc) ? (T)((double)Xc[(long)gp * ldc + kk[u]] * sc[u]) : (T)0;
+            pok[u] = pp[u] >= 0 && gp < nc;
+            pf[u] = Xc[(long)min(max(gp, 0), nc - 1) * ldc + kk[u]];
         }
     };
     auto store_cols = [&](T* dst) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u)
-            if (pp[u] >= 0) dst[kk[u] * KT + pp[u]] = pf[u];
+            if (pp[u] >= 0) dst[kk[u] * KT + pp[u]] = pok[u] ? (T)((double)pf[u] * sc[u]) : (T)0;
     };
     load_cols(tcs);
     stage_points(xr, Xr, ldr, nr, tr * KT, d, tid, scale, fast ? 2.0 : 1.0);
@@ -456,7 +461,10 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
     }
     const int c0 = col0 / KT, c1 = col1 / KT, W = c1 - c0, TR = rows_pad / KT;
     // strips of up to S tiles of one tile row per workgroup (PG_KB_STRIP; 1 = one tile per workgroup, round 2's granularity)
-    static const int strip_env = getenv("PG_KB_STRIP") ? atoi(getenv("PG_KB_STRIP")) : 8;
+    // Re-swept with the fast body and the true prefetch (N = 16384, d = 8, lower-only / mirrored, ms): S = 1: 0.326 / 0.561, 2: 0.265 / 0.477,
+    // 3: 0.236 / 0.411, 4: 0.224 / 0.406, 5: 0.214 / 0.394, 6: 0.213 / 0.397, 8: 0.233 / 0.424, 12: 0.224 / 0.425, 16: 0.239 / 0.429,
+    // 32: 0.259 / 0.459 -- strips whose rows are NOT a multiple of 4 KB long do best (concurrent workgroups spread over the channels)
+    static const int strip_env = getenv("PG_KB_STRIP") ? atoi(getenv("PG_KB_STRIP")) : 6;
     const int S = std::max(1, std::min(strip_env, 64));
     const int SW = (W + S - 1) / S;
     // symmetric: the triangle of the window's own tile rows plus the rectangle below it; cross build: every tile of the window
