@@ -691,7 +691,7 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
         if (early && tid == 0) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody may wait for it
         return;
     }
-    if (tid == 0) { fail = 0; *ecnt = 0; }
+    if (tid == 0) { fail = 0; *ecnt = 0; ecnt[1] = 0; }
     {   // lower triangle -> LDS, two columns per thread, 64 pairs per row; all loads are issued before the first use
         constexpr int NLD = (NB * NB / 2 + NTH - 1) / NTH;
         pair_t v[NLD];
@@ -762,6 +762,11 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             // the factor takes 5100-5400 clocks either way; default 1)
             const int first_bad = leaf3_factor_diag<T>((typename LdsPtr<T>::type)(S + c0 * LD + c0), (typename LdsPtr<T>::type)(Dinv + jb * 16 * DLD),
                                                        lane, wave == 0);
+            // (s_setprio 3 around the factor: no change, n = 4096 1.473 vs 1.480 ms)
+            if (wave == 0 && lane == 0) {
+                if (tlog) tlog[35 + jb] = wall_clock64();                                  // the factor alone (probe_cs_tlog.py)
+                if (nf3 & 64) __hip_atomic_store(ecnt + 1, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (wave == 0 && first_bad < 16 && lane == 0) { fail = 1; atomicCAS(info, 0, col0 + c0 + first_bad + 1); }
         }
         __syncthreads();                                               // B: D and D^-1 of this step are published
@@ -818,6 +823,11 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
                 for (int r = 0; r < 4; ++r) S[(r0 + fr) * LD + c0 + Mfma<T>::row(lane, r)] = x0[r];
             }
         } else if (worker) {
+            // (bit 6, PG_LEAF3_DIAG=1: timing diagnostic -- the slot's work starts only when the factor beside it has finished, so the
+            // stamps give both durations without the other's interference)
+            if (nf3 & 64) {
+                while (__hip_atomic_load(ecnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + 2) __builtin_amdgcn_s_sleep(2);
+            }
             // ---- beside the next step's factor: the rest of this step's trailing update (tiles (ti, tj), 1 <= tj <= ti), block row
             // jb of the inverse (its D^-1 exists since B), and -- in the last such slot -- the sums of the inverse's last block row
             const int nrest = nt * (nt - 1) / 2;
@@ -986,7 +996,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     long long* tl = getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr;
     if (abl & 64) {
         static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
-                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16);
+                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16) |
+                               ((getenv("PG_LEAF3_DIAG") && atoi(getenv("PG_LEAF3_DIAG"))) ? 64 : 0);
         if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         PG_CHECK(hipGetLastError());
@@ -1021,7 +1032,8 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
     }
     if ((ablate & 64) && form != 1 && !(ablate & 15)) {      // third form (no ablation switches)
         static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
-                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16);
+                               ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16) |
+                               ((getenv("PG_LEAF3_DIAG") && atoi(getenv("PG_LEAF3_DIAG"))) ? 64 : 0);
         hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
         PG_CHECK(hipGetLastError());
         return 0;

@@ -33,7 +33,7 @@ for k in range(1, min(nblk - 1, 14)):
         (L[5] - L[3]) / 100, (L[6] - L[5]) / 100, (L[7] - L[6]) / 100, (L[8] - L[7]) / 100, (L[9] - L[8]) / 100, (L[10] - L[9]) / 100,
         (tl[k + 1][1] - L[10]) / 100))
 
-print("leaf phases (us): load | per micro-panel: step (tall panel + deferred/inverse), first update column | tail to body-end")
+print("leaf phases (us): load | per micro-panel: step (F: the diagonal block's factor alone, wave 0), first update column | tail to body-end")
 for k in range(1, min(nblk - 1, 10)):
     L = tl[k]
     parts = ["load %.1f" % ((L[16] - L[1]) / 100)]
@@ -41,7 +41,7 @@ for k in range(1, min(nblk - 1, 10)):
     for jb in range(8):
         a = L[17 + 2 * jb]
         b = L[18 + 2 * jb] if jb < 7 else a
-        parts.append("%d: %.2f+%.2f" % (jb, (a - prev) / 100, (b - a) / 100))
+        parts.append("%d: %.2f(F %.2f)+%.2f" % (jb, (a - prev) / 100, (L[35 + jb] - prev) / 100, (b - a) / 100))
         prev = b
     parts.append("finish %.2f, last stores %.2f" % ((L[34] - prev) / 100, (L[2] - L[34]) / 100))
     print("%3d " % k + " | ".join(parts))
