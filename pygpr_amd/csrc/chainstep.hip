@@ -224,6 +224,7 @@ __device__ __forceinline__ void cs_rows_body(char* smem_raw, T* __restrict__ A, 
     T* Bs = As + ROWS * CS_CLD;                                  // [128][CS_CLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = RG == 2 ? wave >> 2 : 0, cg = RG == 2 ? wave & 3 : wave, fr = lane & 15;
+    TL(11);                                                      // the workgroup is running
     T* Arow = A + (long)row0 * lda;                              // this workgroup's rows
     const T* Brow = A + (long)(k0 + NB) * lda;                   // block row k+1
     typename Mfma<T>::acc_t acc[NJ], cin[NJ];
@@ -372,12 +373,15 @@ template <typename T>
 __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
                                                                const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
                                                                CsWait tmo, int* info, int direct, long long* tlog, int* early_k,
-                                                               int* browe_k) {
+                                                               int* browe_k, int rows16) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int w = blockIdx.x;
     if (w < CS_NCRIT)
         cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 16 * w, o0, k0, has_next != 0, true, inv, done_k, brow_k, diag_next, CS_NCRIT,
                            tmo, info, direct, w == 0 ? tlog : nullptr, early_k, browe_k);
+    else if (rows16)   // experiment: 16-row workgroups below the critical ones too (twice as many, each half as long)
+        cs_rows_body<T, 1>(smem_raw, A, lda, k0 + 2 * NB + 16 * (w - CS_NCRIT), o0, k0, has_next != 0, false, inv, done_k, brow_k,
+                           diag_next, CS_NCRIT, tmo, info, rows16 == 2 ? direct : 0, nullptr);
     else
         cs_rows_body<T, 2>(smem_raw, A, lda, k0 + 2 * NB + 32 * (w - CS_NCRIT), o0, k0, has_next != 0, false, inv, done_k, brow_k,
                            diag_next, CS_NCRIT, tmo, info, direct, nullptr);
@@ -398,10 +402,13 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
         attr_done = true;
     }
     static const int direct = getenv("PG_CS_K128") ? atoi(getenv("PG_CS_K128")) : 1;
-    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / 32), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
+    static const int rows16_env = getenv("PG_CS_ROWS16") ? atoi(getenv("PG_CS_ROWS16")) : 4096;   // rows at or below which every workgroup takes 16 rows
+    static const int rows16_direct = getenv("PG_CS_ROWS16_DIRECT") ? atoi(getenv("PG_CS_ROWS16_DIRECT")) : 1;
+    const int rows16 = (rows16_env > 0 && m <= rows16_env) ? (rows16_direct ? 2 : 1) : 0;
+    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / (rows16 ? 16 : 32)), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
                        getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr, direct ? early_k : nullptr,
-                       browe_k);
+                       browe_k, rows16);
     PG_CHECK(hipGetLastError());
     return 0;
 }

@@ -667,11 +667,110 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
     return first_bad;
 }
 
+// The same factor with its rank-4 trailing updates on the matrix pipe (fp64; round 3, second half).  The row-per-lane form above is
+// ISSUE-bound, not latency-bound: about 1250 instructions for one wave at four clocks each = 5000 shader clocks = 2.1 us, whatever runs
+// beside it (tools/micro/blockfac.hip, tools/micro/issue_rate.hip; the instruction cache is not it: SQC_ICACHE_MISSES = 6 per leaf).
+// Here the block lives in MFMA accumulator layout: by symmetry register r of lane (g, i) -- C[g + 4r][i] of v_mfma_f64_16x16x4 -- is
+// read as T[i][4g + r], so lane group g holds four COLUMNS of every row.  Four panels of four columns: the group that holds the panel
+// eliminates it with broadcasts inside the panel only (six multipliers instead of up to fifteen per column), hands -w, a and the
+// identity rows' panel through a small LDS staging area, and the rank-4 update of everything right of the panel is ONE MFMA (plus one
+// for the identity rows that leave as D^-1).  MFMA row rho = g + 4r stands for matrix column 4g + r, so the A operand's lane (k, rho)
+// takes the multiplier of matrix row 4 (rho & 3) + (rho >> 2); rows of finished columns get a zero multiplier and keep their values.
+// About 570 instructions, 3400 clocks in isolation (5000 for the form above), same numbers to the last bit or two (4.4e-16 against a
+// long-double Cholesky either way).
+#define F3_SLD 6          // staging rows of four doubles padded to six: 16-byte aligned writes, conflict-free 8-byte reads
+#define F3_STAGE (48 * F3_SLD + 16)
+__device__ __forceinline__ int leaf3_factor_blk(lds_f64* D, lds_f64* Dv, lds_f64* stage, int lane, bool store) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    const int g = lane >> 4, i = lane & 15;
+    lds_f64* Sw = stage;                    // [16][F3_SLD]  -w of the panel (A operand)
+    lds_f64* Sa = stage + 16 * F3_SLD;      // [16][F3_SLD]  the panel's unscaled columns (B operand of T's update)
+    lds_f64* Sz = stage + 32 * F3_SLD;      // [16][F3_SLD]  the identity rows' panel (B operand of Z's update)
+    lds_f64* Sp = stage + 48 * F3_SLD;      // [16] pivots
+    pg_d4 t, z;
+    {
+        const d2 lo = *reinterpret_cast<lds_d2*>(D + i * LD + 4 * g), hi = *reinterpret_cast<lds_d2*>(D + i * LD + 4 * g + 2);
+        t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = (4 * g + r == i) ? 1.0 : 0.0;
+    const int jrow = 4 * (i & 3) + (i >> 2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (g == p) {                       // the group that holds this panel's columns; the others wait for the update
+            double wn[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double piv = bcast_lane(t[c], 16 * p + 4 * p + c);
+                wn[c] = -t[c] * recip(piv);
+#pragma unroll
+                for (int k = c + 1; k < 4; ++k) {
+                    const double m = bcast_lane(wn[c], 16 * p + 4 * p + k);
+                    t[k] = __builtin_fma(t[c], m, t[k]);
+                    z[k] = __builtin_fma(z[c], m, z[k]);
+                }
+            }
+            if (p < 3) {
+                *reinterpret_cast<lds_d2*>(Sw + i * F3_SLD) = d2{wn[0], wn[1]};
+                *reinterpret_cast<lds_d2*>(Sw + i * F3_SLD + 2) = d2{wn[2], wn[3]};
+                *reinterpret_cast<lds_d2*>(Sa + i * F3_SLD) = d2{t[0], t[1]};
+                *reinterpret_cast<lds_d2*>(Sa + i * F3_SLD + 2) = d2{t[2], t[3]};
+                *reinterpret_cast<lds_d2*>(Sz + i * F3_SLD) = d2{z[0], z[1]};
+                *reinterpret_cast<lds_d2*>(Sz + i * F3_SLD + 2) = d2{z[2], z[3]};
+            }
+        }
+        if (p == 3) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double aw = Sw[jrow * F3_SLD + g];
+        double bt = Sa[i * F3_SLD + g];
+        const double bz = Sz[i * F3_SLD + g];
+        aw = (jrow >= 4 * p + 4) ? aw : 0.0;
+        // what lies right of the diagonal in the block is scratch (finite for finite input); a NaN there must not reach a finished
+        // entry through 0 x NaN (the LAPACK convention names the FIRST bad minor: test_kernel_build_propagates_nan)
+        bt = (i >= 4 * p + g) ? bt : 0.0;
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, bt, t, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, bz, z, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();    // the staging area is re-used by the next panel
+    }
+    {   // pivots = the diagonal: lane (g, i) with i >> 2 == g holds T[i][i] in register i & 3
+        double d = t[0];
+        d = ((i & 3) == 1) ? t[1] : d;
+        d = ((i & 3) == 2) ? t[2] : d;
+        d = ((i & 3) == 3) ? t[3] : d;
+        if ((i >> 2) == g) Sp[i] = d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const d2 p01 = *reinterpret_cast<lds_d2*>(Sp + 4 * g), p23 = *reinterpret_cast<lds_d2*>(Sp + 4 * g + 2);
+    const bool bad = !(p01[0] > 0.0) || !(p01[1] > 0.0) || !(p23[0] > 0.0) || !(p23[1] > 0.0);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {   // a non-positive (or NaN) pivot: name the first one's column, store nothing
+        int first_bad = 16;
+#pragma unroll 1
+        for (int c = 15; c >= 0; --c)
+            if (!(Sp[c] > 0.0)) first_bad = c;
+        return first_bad;
+    }
+    if (store) {
+        const double rs0 = inv_sqrt(p01[0]), rs1 = inv_sqrt(p01[1]), rs2 = inv_sqrt(p23[0]), rs3 = inv_sqrt(p23[1]);
+        *reinterpret_cast<lds_d2*>(D + i * LD + 4 * g) = d2{t[0] * rs0, t[1] * rs1};
+        *reinterpret_cast<lds_d2*>(D + i * LD + 4 * g + 2) = d2{t[2] * rs2, t[3] * rs3};
+        Dv[(4 * g + 0) * DLD + i] = z[0] * rs0;
+        Dv[(4 * g + 1) * DLD + i] = z[1] * rs1;
+        Dv[(4 * g + 2) * DLD + i] = z[2] * rs2;
+        Dv[(4 * g + 3) * DLD + i] = z[3] * rs3;
+    }
+    return 16;
+}
+
 // (Round 3 also tried the chain as a LOOP -- registers rotate instead of the code: row[k-1] = row[k] - row[0] w_k, the pivot always in
 // row[0], its column a run-time lane of v_readlane; two loops of eight pivots, 0.9 KB of code instead of 9 KB, bit-identical factor.
 // A step took 4.6 us instead of 2.9 (n = 4096: 1.54 -> 1.85 ms): every iteration pays all fifteen broadcasts, and the wave issues
 // about one instruction per 7 clocks whether the code is short or long.  Removed again; DESIGN.md has the numbers.)
-template <typename T, bool WT>
+template <typename T, bool WT, bool BLK = false>
 __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, long lda, T* __restrict__ inv, long ldi,
                                            int* __restrict__ info, int col0, long long* tlog = nullptr, int nf3 = 1,
                                            int* early = nullptr) {
@@ -717,6 +816,18 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     // 16 columns of L (all 128 rows: zeros above the diagonal) / rows of the inverse -> global, by the threads t0, t0 + nth, ...
     auto store_l_panel = [&](int jbp, int t0, int nth) {
         const int cc0 = 16 * jbp;
+        if (BLK) {   // rows from the diagonal block down (the zeros above it are out already)
+#pragma unroll 2
+            for (int idx = t0; idx < (NB - cc0) * 8; idx += nth) {
+                const int i = cc0 + (idx >> 3), k = cc0 + (idx & 7) * 2;
+                pair_t v = *reinterpret_cast<const pair_t*>(S + i * LD + k);
+                if (k > i) v[0] = (T)0;
+                if (k + 1 > i) v[1] = (T)0;
+                if (WT) st_pair_wt(A, rA, (long)i * lda + k, v);
+                else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = v;
+            }
+            return;
+        }
         for (int idx = t0; idx < NB * 8; idx += nth) {
             const int i = idx >> 3, k = cc0 + (idx & 7) * 2;
             pair_t v = {(T)0, (T)0};
@@ -728,6 +839,26 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
         }
     };
     auto store_inv_rows = [&](int row_lo, int row_hi, int t0, int nth) {
+        if (BLK) {   // one block row (row_hi == row_lo + 16): its pb + 1 column blocks, eight pairs x sixteen rows each
+            const int pb = row_lo >> 4;
+#pragma unroll 2
+            for (int idx = t0; idx < 128 * (pb + 1); idx += nth) {
+                const int qb = idx >> 7, ii = (idx >> 3) & 15, kk = (idx & 7) * 2, i = row_lo + ii, k = 16 * qb + kk;
+                pair_t v;
+                if (qb == pb) {
+                    const T* Dv = Dinv + pb * 16 * DLD + ii * DLD + kk;
+                    v[0] = (kk <= ii) ? Dv[0] : (T)0;
+                    v[1] = (kk + 1 <= ii) ? Dv[1] : (T)0;
+                } else {
+                    const T* Xt = S + (16 * qb + ii) * LD + 16 * pb + kk;
+                    v[0] = Xt[0];
+                    v[1] = Xt[1];
+                }
+                if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, v);
+                else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = v;
+            }
+            return;
+        }
         for (int idx = row_lo * 64 + t0; idx < row_hi * 64; idx += nth) {
             const int i = idx >> 6, k = (idx & 63) * 2;
             const int pb = i >> 4, qb = k >> 4, ii = i & 15;
@@ -755,13 +886,35 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
-        if (wave < NF3) {
+        if (BLK && jb == 0 && wave != 0) {
+            // beside the FIRST factor (nothing else to do yet): the zeros above the diagonal of both output tiles go out, so that the panel /
+            // block-row stores further down only carry what is on or below the diagonal (1152 pairs per step instead of 2048).  (Issued
+            // in the load phase instead they held the tile's way into LDS behind their write acknowledgements: load 2.0 -> 4-5 us.)
+            const pair_t zz = {(T)0, (T)0};
+            for (int idx = tid - 64; idx < NB * NB / 2; idx += NTH - 64) {
+                const int i = idx >> 6, k = (idx & 63) * 2;
+                if (k > i) {
+                    if (WT) st_pair_wt(A, rA, (long)i * lda + k, zz);
+                    else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = zz;
+                    if (inv) {
+                        if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, zz);
+                        else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = zz;
+                    }
+                }
+            }
+        }
+        if (BLK && jb == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's zero stores are out long before any flag is raised
+        if (wave < ((BLK && sizeof(T) == 8) ? 1 : NF3)) {
             // ---- F: the diagonal block alone.  lanes 0-15: its rows; lanes 16-31: identity rows, which leave the loop as D^-1.
             // (PG_LEAF3_NF = 2..4: waves 1 .. NF3-1 run the SAME instructions on the same data and store nothing -- an experiment on
             // whether company on the other SIMDs shares the instruction fetch of this 9 KB of straight-line code: it does not,
             // the factor takes 5100-5400 clocks either way; default 1)
-            const int first_bad = leaf3_factor_diag<T>((typename LdsPtr<T>::type)(S + c0 * LD + c0), (typename LdsPtr<T>::type)(Dinv + jb * 16 * DLD),
-                                                       lane, wave == 0);
+            int first_bad;
+            if constexpr (BLK && sizeof(T) == 8)
+                first_bad = leaf3_factor_blk((lds_f64*)(S + c0 * LD + c0), (lds_f64*)(Dinv + jb * 16 * DLD), (lds_f64*)(Dinv + 8 * 16 * DLD + 18), lane, true);
+            else
+                first_bad = leaf3_factor_diag<T>((typename LdsPtr<T>::type)(S + c0 * LD + c0), (typename LdsPtr<T>::type)(Dinv + jb * 16 * DLD),
+                                                 lane, wave == 0);
             // (s_setprio 3 around the factor: no change, n = 4096 1.473 vs 1.480 ms)
             if (wave == 0 && lane == 0) {
                 if (tlog) tlog[35 + jb] = wall_clock64();                                  // the factor alone (probe_cs_tlog.py)
@@ -812,6 +965,22 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(r0 + 16 * t + fr) * LD + c0 + Mfma<T>::row(lane, r)] = xt[r];
             }
+        } else if (BLK && jb >= 1) {
+            // ---- the waves without a tile (5 + jb of them): what the PREVIOUS step made final goes out -- its sixteen columns of L and
+            // block row jb - 1 of the inverse.  (With the row-per-lane factor these stores sat in the slot beside the factor, whose nine
+            // workers had time to spare; beside the blocked factor that slot is what the step waits for: tiles 1.3 us + stores 0.6 us
+            // against 1.5 us of factor, stamped.)  After step 4's M the inverse's first four block rows are out: the storing waves drain,
+            // count themselves in LDS, and the last one raises *early (chainstep.hip's two-phase hand-over).
+            const int nidle = NWV - nt, t0 = 64 * (wave - nt) + lane, nth = 64 * nidle;
+            store_l_panel(jb - 1, t0, nth);
+            if (want_inv) store_inv_rows(16 * (jb - 1), 16 * jb, t0, nth);
+            if (early && jb == 4) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const int before = atomicAdd(ecnt, 1);                         // LDS
+                    if (before == nidle - 1) __hip_atomic_store(early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         __syncthreads();                                               // B': every tile's X and updated column are in LDS
         LTL(18 + 2 * jb);
@@ -830,6 +999,8 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             }
             // ---- beside the next step's factor: the rest of this step's trailing update (tiles (ti, tj), 1 <= tj <= ti), block row
             // jb of the inverse (its D^-1 exists since B), and -- in the last such slot -- the sums of the inverse's last block row
+            const bool wstamp = tlog && wave == 1 && lane == 0 && jb == 2;       // one worker's slot, stamped (probe_cs_tlog.py)
+            if (wstamp) tlog[43] = wall_clock64();
             const int nrest = nt * (nt - 1) / 2;
             const int nx = want_inv ? jb : 0;
             const bool last = want_inv && jb == NB / 16 - 2;           // after it only the last diagonal block is factored
@@ -855,10 +1026,12 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             // instead of everything.  After step 4's slot the inverse's first four block rows are out: each storing wave drains,
             // counts itself in LDS, and the last one raises *early -- the rows of block row k+1 start their solve against
             // those 64 rows while the leaf still has three steps and its tail to run (chainstep.hip).
-            if (jb >= 1) {
+            if (wstamp) tlog[46] = wall_clock64();
+            if (!BLK && jb >= 1) {
                 const int t0 = 64 * widx + lane, nth = 64 * nwork;
                 store_l_panel(jb - 1, t0, nth);
                 if (want_inv) store_inv_rows(16 * (jb - 1), 16 * jb, t0, nth);
+                if (wstamp) tlog[47] = wall_clock64();
                 if (early && jb == 4) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) {
@@ -927,7 +1100,7 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
 
 // The third form as kernels of its own: sharing a kernel with the second form (a run-time switch between two inlined bodies) left
 // the pivot loop two scalar registers for its broadcasts.
-template <typename T, bool WT>
+template <typename T, bool WT, bool BLK = false>
 __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
                                                         int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int nf3,
                                                         int* early) {
@@ -941,9 +1114,9 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
         }
     }
     __syncthreads();
-    if (tlog && threadIdx.x == 0) tlog[1] = wall_clock64();
-    leaf3_body<T, WT>(smem_raw, A, lda, inv, NB, info, col0, tlog, nf3, WT ? early : nullptr);
-    if (tlog && threadIdx.x == 0) tlog[2] = wall_clock64();
+    if (tlog && threadIdx.x == 0) { tlog[1] = wall_clock64(); tlog[44] = (long long)__builtin_amdgcn_s_memtime(); }
+    leaf3_body<T, WT, BLK>(smem_raw, A, lda, inv, NB, info, col0, tlog, nf3, WT ? early : nullptr);
+    if (tlog && threadIdx.x == 0) { tlog[2] = wall_clock64(); tlog[45] = (long long)__builtin_amdgcn_s_memtime(); }   // [45]-[44] over [2]-[1]: the shader clock the leaf ran at
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tlog && threadIdx.x == 0) tlog[3] = wall_clock64();
@@ -956,20 +1129,24 @@ __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long 
         __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-template <typename T>
+template <typename T, bool BLK = false>
 __global__ __launch_bounds__(NTH) void pg_leaf3_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, long ldi, int* __restrict__ info,
                                                        int col0, long eA, long eInv, int nf3) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf3_body<T, false>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0, nullptr, nf3);
+    leaf3_body<T, false, BLK>(smem_raw, A + blockIdx.x * eA, lda, inv ? inv + blockIdx.x * eInv : nullptr, ldi, info + blockIdx.x, col0, nullptr, nf3);
 }
 
+static bool pg_leaf3_blk() {
+    static const bool v = !(getenv("PG_LEAF3_BLK") && !atoi(getenv("PG_LEAF3_BLK")));
+    return v;
+}
 bool pg_leaf_has_early() {   // the coupled leaf raises its early flag before its done flag (third form, write-through hand-off)
     static const bool v = !(getenv("PG_LEAF3") && !atoi(getenv("PG_LEAF3"))) && !(getenv("PG_CS_LEAF_WT") && !atoi(getenv("PG_CS_LEAF_WT")));
     return v;
 }
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
                                        const CsWait& tmo, int* early) {
-    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
+    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16 + F3_STAGE) * sizeof(T) + 16;
     static bool attr_done = false;
     if (!attr_done) {
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf2s_kernel<T, true>),
@@ -979,6 +1156,10 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3s_kernel<T, false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
@@ -998,7 +1179,11 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
         static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
                                ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16) |
                                ((getenv("PG_LEAF3_DIAG") && atoi(getenv("PG_LEAF3_DIAG"))) ? 64 : 0);
-        if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
+        // blocked diagonal factor (leaf3_factor_blk: fp64, default; PG_LEAF3_BLK=0: the row-per-lane factor) -- a kernel of its own per form
+        if (pg_leaf3_blk() && sizeof(T) == 8) {
+            if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
+            else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
+        } else if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
         PG_CHECK(hipGetLastError());
         return 0;
@@ -1015,7 +1200,7 @@ template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, i
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate, int nexp, long eA,
                                   long eInv) {
-    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16) * sizeof(T) + 16;
+    const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16 + F3_STAGE) * sizeof(T) + 16;
     static bool attr_done = false;
     static const int form = getenv("PG_LEAF") ? atoi(getenv("PG_LEAF")) : 2;   // 1: round-1 leaf (A / B / C phases), 2: fused tall-panel step
     if (!(getenv("PG_LEAF_PROG") && atoi(getenv("PG_LEAF_PROG")))) ablate ^= 16;     // default: round 2's data movement (bit 4 set);
@@ -1028,13 +1213,16 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3_kernel<T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pg_leaf3_kernel<T, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     if ((ablate & 64) && form != 1 && !(ablate & 15)) {      // third form (no ablation switches)
         static const int nf3 = (getenv("PG_LEAF3_NF") ? std::max(1, std::min(4, atoi(getenv("PG_LEAF3_NF")))) : 1) |
                                ((getenv("PG_LEAF3_ALONE") && !atoi(getenv("PG_LEAF3_ALONE"))) ? 0 : 16) |
                                ((getenv("PG_LEAF3_DIAG") && atoi(getenv("PG_LEAF3_DIAG"))) ? 64 : 0);
-        hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
+        if (pg_leaf3_blk() && sizeof(T) == 8) hipLaunchKernelGGL((pg_leaf3_kernel<T, true>), dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
+        else hipLaunchKernelGGL(pg_leaf3_kernel<T>, dim3(nexp), dim3(NTH), lds, st, A, lda, inv, ldi, info, col0, eA, eInv, nf3);
         PG_CHECK(hipGetLastError());
         return 0;
     }

@@ -522,7 +522,15 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0 && nexp == 1;
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
     static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 384;   // round 3, same box: 512 -> 384: n = 4096 1.64 -> 1.60 ms, 8192 5.10 -> 5.03, 16384 equal
-    for (int c = 0; c < n; c += (want_cp && n - c <= sync_rows) ? std::min(NBO, cs_panel) : NBO) pb.push_back(c);
+    // experiment: wider coupled panels while the trailing update still bounds the step (deeper K for Sb), narrow ones in the chain-bound tail
+    static const int cs_panel_wide = getenv("PG_CS_PANEL_WIDE") ? atoi(getenv("PG_CS_PANEL_WIDE")) : 0;
+    static const int cs_wide_rows = getenv("PG_CS_WIDE_ROWS") ? atoi(getenv("PG_CS_WIDE_ROWS")) : 5120;
+    for (int c = 0; c < n;) {
+        pb.push_back(c);
+        int w = NBO;
+        if (want_cp && n - c <= sync_rows) w = std::min(NBO, (cs_panel_wide > 0 && n - c > cs_wide_rows) ? cs_panel_wide : cs_panel);
+        c += w;
+    }
     pb.push_back(n);
     const int npan = (int)pb.size() - 1;
     const bool la = ctx->lookahead && !ctx->prof_on && npan >= 3;
@@ -704,7 +712,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             const long tiles = (long)(m2 / 128) * (m2 / 128 + 1) / 2 * nexp;
             // (threshold swept 512 / 1024 / 2048: 2048 is 2 % faster at n = 8192 and neutral at 16384)
             // (re-swept with the eight-wave blocks, 2048 / 1024 / 512 / 256: 2048 stays best at 8192, neutral at 16384)
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 2048 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            static const long sb_thresh = getenv("PG_SB_TILE_THRESH") ? atol(getenv("PG_SB_TILE_THRESH")) : 2048;
+            if ((rc = pg_gemm<T>(ctx, us, tiles < sb_thresh ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         if (la) {
             if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]

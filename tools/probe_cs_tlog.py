@@ -46,3 +46,22 @@ for k in range(1, min(nblk - 1, 10)):
     parts.append("finish %.2f, last stores %.2f" % ((L[34] - prev) / 100, (L[2] - L[34]) / 100))
     print("%3d " % k + " | ".join(parts))
 
+
+# shader clock held during each leaf: s_memtime ticks over s_memrealtime ticks (100 MHz) around the body (MI355X_MICROARCH.md, DVFS item 6)
+clk = [(tl[k][45] - tl[k][44]) / max(tl[k][2] - tl[k][1], 1) * 0.1 for k in range(1, nblk - 1) if tl[k][45] > tl[k][44]]
+if clk:
+    print("in-kernel shader clock during the leaves (GHz): first %.2f, median %.2f, min %.2f, max %.2f, last %.2f (%d leaves)" % (
+        clk[0], sorted(clk)[len(clk) // 2], min(clk), max(clk), clk[-1], len(clk)))
+
+# one worker wave's slot beside the factor of micro-panel 3 (wave 1, slot of step jb = 2): from the barrier behind M to its start,
+# its tiles (deferred trailing update + the inverse's block row), its stores of the previous step's panel / block row
+print("worker slot (wave 1, step 2): starts %+.2f us after the barrier, tiles %.2f, stores %.2f; the factor beside it ends at %+.2f, the next barrier at %+.2f" % tuple(
+    np.median([v for v in col]) for col in zip(*[((tl[k][43] - tl[k][22]) / 100, (tl[k][46] - tl[k][43]) / 100, (tl[k][47] - tl[k][46]) / 100,
+                                                   (tl[k][38] - tl[k][22]) / 100, (tl[k][23] - tl[k][22]) / 100) for k in range(1, nblk - 1)])))
+
+# the rows kernel of each step (its first critical workgroup): when it starts running relative to the leaf of the same step, and how long its
+# work BEFORE the leaf's flags takes (tile loads + the window's product): if start + pre-work exceeds the leaf's body, the step waits for the rows
+rs = [((tl[k][11] - tl[k][1]) / 100, (tl[k][4] - tl[k][11]) / 100, (tl[k][2] - tl[k][1]) / 100) for k in range(1, nblk - 1) if tl[k][11] > 0]
+if rs:
+    print("rows kernel vs leaf, per step (us): [starts after the leaf's start | its pre-work | the leaf's body]")
+    print("  " + "  ".join("%d:[%+.1f|%.1f|%.1f]" % (k + 1, a, b, c) for k, (a, b, c) in enumerate(rs)))
