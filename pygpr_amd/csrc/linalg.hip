@@ -588,9 +588,17 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     if (o_s < npan) {
         PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((5 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
     }
+    // Coupled panels while the trailing update still bounds the step (more than `sa_rows` rows right of the panel): the next panel's
+    // columns take this panel's update as ONE product on the update stream ("Sa", then a flag for the next leaf) instead of through the
+    // rows kernels' two-panel window.  There the rows workgroups live on the reserved CUs only (77 KB of LDS do not fit beside the 64 x 64
+    // blocks of the trailing update), and their window products, squeezed onto 32 CUs, took as long as the update itself
+    // (n = 8192, steps 8-10: 34 | 158 | 228 us, the leaf of the next panel not even finding a CU for 190 us).
+    static const int sa_rows = getenv("PG_CS_SA_ROWS") ? atoi(getenv("PG_CS_SA_ROWS")) : 0;   // measured: slower at every setting (n = 8192: off 4.77, 6144: 4.83, 4608: 4.90, 3072: 4.98, 2048: 5.06 ms): the panel period there is the trailing update's own time
+    auto sa_after = [&](int o) { return sa_rows > 0 && o >= o_s && o + 1 < npan && (n - pb[o + 1]) > sa_rows; };
     for (int o = 0; o < npan; ++o) {
         const int o0 = pb[o], oend = pb[o + 1];
         const bool cp = o >= o_s;
+        const bool sa_this = cp && sa_after(o), sa_prev = cp && o > o_s && sa_after(o - 1);
         if (cp) {
             hipStream_t rs = rows_stream;
             if (o == o_s) {
@@ -609,17 +617,23 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 if (n - k0 - NB <= 0) break;
                 const int c = k0 + NB;                       // the block column this step brings up to date
                 const int oc = c < oend ? o : o + 1;         // its panel
-                const int wstart = oc == o_s ? pb[o_s] : pb[oc - 1];   // the classic part applied the panel before the first coupled one
-                if (c == oend && oc >= 2) {                  // first touch of panel oc: Sb(oc - 2) wrote these columns last
+                // the classic part applied the panel before the first coupled one; so does Sa(o - 1) in the update-bound part
+                const int wstart = (oc == o_s || (oc == o && sa_prev)) ? pb[oc] : pb[oc - 1];
+                const bool last_sa = c == oend && sa_this;   // the next panel's first column is Sa(o)'s: this step only solves
+                if (c == oend && oc >= 2 && !last_sa) {      // first touch of panel oc: Sb(oc - 2) wrote these columns last
                     if ((rc = pool_event(ctx, 2 + 2 * (oc - 2) + 1, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
-                if (c == oend && oc == 1 && build_split) {   // first touch of a column the folded build wrote on the update stream
+                if (c == oend && oc == 1 && build_split && !last_sa) {   // first touch of a column the folded build wrote on the update stream
                     if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
-                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info,
-                                        two_phase ? f_early + kb : nullptr, f_browe + kb)))
+                if (k0 == o0 && sa_prev) {                   // this panel's columns were last written by Sa(o - 1) on the update stream
+                    if ((rc = pool_event(ctx, 8 + 2 * npan + (o - 1), &ev))) return rc;
+                    PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+                }
+                if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, last_sa ? 0 : 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info,
+                                        (two_phase && !last_sa) ? f_early + kb : nullptr, f_browe + kb)))
                     return rc;
             }
         }
@@ -682,6 +696,17 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             }
         }
         const int o2 = (o + 2 <= npan) ? pb[o + 2] : n;   // first column right of panel o+1
+        if (sa_this) {   // Sa(o) of a coupled panel: on the update stream (behind ev_chain[o]), then the flag the next panel's first leaf waits for
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;
+            p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1;
+            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            if ((rc = pg_flagset(us, f_diag + oend / NB, PG_CS_NCRIT))) return rc;
+            if ((rc = pool_event(ctx, 8 + 2 * npan + o, &ev))) return rc;
+            PG_CHECK(hipEventRecord(ev, us));
+        }
         if (!cp) {   // Sa(o): panel o+1's columns -= panel o   (coupled panels: part of the rows kernels' left-looking product)
             GemmP<T> p = gp0<T>(); p.info = info;
             p.M = n - oend; p.N = o2 - oend; p.K = oend - o0;

@@ -65,3 +65,9 @@ rs = [((tl[k][11] - tl[k][1]) / 100, (tl[k][4] - tl[k][11]) / 100, (tl[k][2] - t
 if rs:
     print("rows kernel vs leaf, per step (us): [starts after the leaf's start | its pre-work | the leaf's body]")
     print("  " + "  ".join("%d:[%+.1f|%.1f|%.1f]" % (k + 1, a, b, c) for k, (a, b, c) in enumerate(rs)))
+
+# every step of the factorisation at a glance: start of the leaf (us since the first leaf), time to the next leaf's start, and of that the
+# leaf's own wait for its tile -- shows where the update-bound phase (long steps, the chain waiting for the trailing update) ends
+st = [us(tl[k][0]) for k in range(nblk)]
+print("steps: start | to next | leaf waited")
+print("  " + "  ".join("%d:%.0f|%.0f|%.0f" % (k, st[k], st[k + 1] - st[k], (tl[k][1] - tl[k][0]) / 100) for k in range(nblk - 1)))
