@@ -266,6 +266,11 @@ int pg_last_coupled_panels(pg_handle h);
 /* one 128x128 Cholesky leaf (factor + inverse) on its own; ablate != 0 skips phases -- timing diagnostics only */
 int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream);
 
+/* one rows kernel of the flag-coupled chain (chainstep.hip) on its own, every flag it would wait for preset: rows below tile
+ * (k0, k0) of an n x n matrix, window from column o0, inv = a 128 x 128 lower-triangular block; flags: 8 ints of scratch --
+ * timing diagnostics only (tools/probe_rowstep.py) */
+int pg_rowstep_raw(pg_handle h, int dtype, int n, void* A, long lda, int o0, int k0, const void* inv, int* flags, int* info, void* stream);
+
 /* raw MFMA GEMM core, exposed for tests and the roofline micro-benchmark:
  * variant 0: C = a A B^T + b C (128x128 tiles; tri != 0 -> lower tiles only), 2: C = a A B + b C,
  * 3: C = a A^T B + b C.  klo/khi as in csrc/gemm.h. */

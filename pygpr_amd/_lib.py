@@ -81,6 +81,7 @@ _SIGS = {
     "pg_set_coupled_chain": (_i, [_vp, _i]),
     "pg_coupled_chain": (_i, [_vp]),
     "pg_leaf_raw": (_i, [_vp, _i, _vp, _l, _vp, _l, _vp, _i, _vp]),
+    "pg_rowstep_raw": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp]),
     "pg_gemm_raw": (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _l, _vp, _l, _d, _vp, _l, _i, _i, _i, _vp]),
 }
 

@@ -2,6 +2,7 @@
 #include "gemm.h"
 #include "kbuild.h"
 #include "leaf.h"
+#include "chainstep.h"
 #include "linalg.h"
 #include <cstdarg>
 #include <cstdio>
@@ -735,6 +736,18 @@ int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, 
     NEED(h && A && info, "null pointer");
     DISPATCH(dtype, pg_leaf<double>(ST(stream), (double*)A, lda, (double*)inv, ldi, info, 0, ablate),
              pg_leaf<float>(ST(stream), (float*)A, lda, (float*)inv, ldi, info, 0, ablate));
+}
+
+int pg_rowstep_raw(pg_handle h, int dtype, int n, void* A, long lda, int o0, int k0, const void* inv, int* flags, int* info, void* stream) {
+    JOIN(h, stream);
+    NEED(h && A && inv && flags && info, "null pointer");
+    NEED(n % 128 == 0 && k0 % 128 == 0 && o0 % 128 == 0 && o0 <= k0 && k0 + 128 < n, "bad shape");
+    // every flag the kernel waits for is already up (64 >= any count): the kernel alone, nothing to wait for
+    PG_CHECK(hipMemsetAsync(flags, 0x40, 8 * sizeof(int), ST(stream)));
+    PG_CHECK(hipMemsetAsync(flags + 6, 0, 2 * sizeof(int), ST(stream)));   // [6]: time-out word, [7]: spare
+    const CsWait cw = {flags + 6, nullptr, 200000000LL, 1};
+    DISPATCH(dtype, pg_rowstep<double>(ST(stream), (double*)A, lda, n, o0, k0, 1, (const double*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4),
+             pg_rowstep<float>(ST(stream), (float*)A, lda, n, o0, k0, 1, (const float*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4));
 }
 
 int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,

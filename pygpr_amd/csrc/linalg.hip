@@ -702,10 +702,22 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.A = A + (long)oend * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)oend * lda + oend; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1;
             const long tiles = (long)(p.M / 128) * (p.N / 128);
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
-            if ((rc = pg_flagset(us, f_diag + oend / NB, PG_CS_NCRIT))) return rc;
+            // PG_CS_SA_STREAM=1: on the ROWS stream behind the panel's last rows kernel (no event towards the next panel's rows kernels;
+            // the update stream keeps nothing but the trailing updates, so Sa(o + 1) does not queue behind Sb(o))
+            static const int sa_on_rows = getenv("PG_CS_SA_STREAM") ? atoi(getenv("PG_CS_SA_STREAM")) : 0;
+            hipStream_t ss = sa_on_rows ? rows_stream : us;
+            if (sa_on_rows && o >= 1) {   // these columns were last written by Sb(o - 1)
+                if ((rc = pool_event(ctx, 2 + 2 * (o - 1) + 1, &ev))) return rc;
+                PG_CHECK(hipStreamWaitEvent(ss, ev, 0));
+            }
+            if (sa_on_rows && o == 0 && build_split) {
+                if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
+                PG_CHECK(hipStreamWaitEvent(ss, ev, 0));
+            }
+            if ((rc = pg_gemm<T>(ctx, ss, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            if ((rc = pg_flagset(ss, f_diag + oend / NB, PG_CS_NCRIT))) return rc;
             if ((rc = pool_event(ctx, 8 + 2 * npan + o, &ev))) return rc;
-            PG_CHECK(hipEventRecord(ev, us));
+            PG_CHECK(hipEventRecord(ev, ss));
         }
         if (!cp) {   // Sa(o): panel o+1's columns -= panel o   (coupled panels: part of the rows kernels' left-looking product)
             GemmP<T> p = gp0<T>(); p.info = info;

@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; rm -f gpurun_out/x21_potrf.log
+PG_CS_SA_STREAM=1 PG_CS_SA_ROWS=3072 timeout -k 10 400 python -m pytest tests/test_hip_kernels.py -m gpu -x -q -k "coupled or potrf or fused" > gpurun_out/x21_tests.log 2>&1; rc=$?; echo "tests rc=$rc" >> gpurun_out/x21_tests.log
+if [ $rc -ne 0 ]; then exit 1; fi
+for rep in 1 2; do
+PG_TAG=off timeout -k 10 200 python tools/probe_potrf_quick.py 4096 8192 16384 >> gpurun_out/x21_potrf.log 2>&1
+for r in 2048 3072 4608; do
+PG_TAG=sarows$r PG_CS_SA_STREAM=1 PG_CS_SA_ROWS=$r timeout -k 10 200 python tools/probe_potrf_quick.py 4096 8192 16384 >> gpurun_out/x21_potrf.log 2>&1
+done
+done
+PG_CS_SA_STREAM=1 PG_CS_SA_ROWS=3072 timeout -k 10 200 python tools/probe_cs_tlog.py 8192 > gpurun_out/x21_tlog8192.log 2>&1
