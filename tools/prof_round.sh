@@ -16,3 +16,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/kb_f -- python3 $R/tools/pr
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/kb_w -- python3 $R/tools/probe_kbuild_once.py > $O/kb_w.log 2>&1; echo "kb_w rc=$?"
 python3 $R/tools/kbuild_summary.py $O/kb $O/kb_f $O/kb_w > $O/${RD}_kernel_build_hbm.json; echo "kb summary rc=$?"
 rm -rf $O/bench $O/ss $O/pmc_f $O/pmc_w $O/teardown $O/kb $O/kb_f $O/kb_w
+# the chain from the inside (in-kernel stamps): per-step timeline, leaf phases, rows kernel vs leaf
+python3 $R/tools/probe_cs_tlog.py 4096 > $O/${RD}_potrf_chain_timeline_n4096.txt 2>&1; echo "tlog4096 rc=$?"
+python3 $R/tools/probe_cs_tlog.py 8192 > $O/${RD}_potrf_chain_timeline_n8192.txt 2>&1; echo "tlog8192 rc=$?"
+# the leaf's 16 x 16 factor, old form against blocked form, in isolation; the rows kernel alone
+$R/tools/micro/blockfac > $O/${RD}_leaf_factor_micro.txt 2>&1; echo "blockfac rc=$?"
+python3 $R/tools/probe_rowstep.py > $O/${RD}_rows_kernel_alone.txt 2>&1; echo "rowstep rc=$?"
