@@ -121,6 +121,31 @@ __device__ __forceinline__ void lds_tile_mm(T* C, int ldc, const T* A, int lda, 
     for (int r = 0; r < 4; ++r) C[Mfma<T>::row(lane, r) * ldc + fr] = alpha * acc[r] + beta * cin[r];
 }
 
+// C(16x16) -= A(16x16) B(16x16)^T, all three row-major at leading dimension LD in LDS: the K = 16 update tile of the leaf's deferred
+// trailing update with ALL twelve LDS reads in flight before the first MFMA (lds_tile_mm as compiled read two fragments, waited, ran two
+// MFMAs, read two more, waited, ... and fetched the C tile last: four LDS round trips and four dependent MFMAs in series, 0.6 us per
+// tile stamped inside the leaf).
+template <typename T>
+__device__ __forceinline__ void lds_tile_update16(T* C, const T* A, const T* B, int lane) {
+    typename Mfma<T>::acc_t acc;
+    const int fr = lane & 15, fk = lane >> 4;
+    T cin[4], a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cin[r] = C[Mfma<T>::row(lane, r) * LD + fr];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[q] = A[fr * LD + 4 * q + fk];
+        b[q] = B[fr * LD + 4 * q + fk];
+    }
+    __builtin_amdgcn_sched_barrier(0);          // nothing below moves above the reads' issue
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (T)0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = Mfma<T>::run(a[q], b[q], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[Mfma<T>::row(lane, r) * LD + fr] = cin[r] - acc[r];
+}
+
 // One 16x16 tile of the inverse, X[p][q] (p > q), by one wave: W = sum_{r=q}^{p-1} L[p][r] X[r][q], X[p][q] = -Dinv[p] W.
 // X[r][q] for r > q is read from upper tile (q, r); the result goes to upper tile (q, p) (also the scratch for W).
 // The two halves are also available on their own: the sum only needs block row p of L and the rows of X above it, so
@@ -678,6 +703,7 @@ __device__ __forceinline__ int leaf3_factor_diag(typename LdsPtr<T>::type D, typ
 // takes the multiplier of matrix row 4 (rho & 3) + (rho >> 2); rows of finished columns get a zero multiplier and keep their values.
 // About 570 instructions, 3400 clocks in isolation (5000 for the form above), same numbers to the last bit or two (4.4e-16 against a
 // long-double Cholesky either way).
+#define SLOT_STORES_FROM 8   // blocked form: the previous step's panel / block row is stored by the solve phase's tile-less waves (8: always; from step 3 on by the slot's workers instead: measured equal, the work only moves)
 #define F3_SLD 6          // staging rows of four doubles padded to six: 16-byte aligned writes, conflict-free 8-byte reads
 #define F3_STAGE (48 * F3_SLD + 16)
 __device__ __forceinline__ int leaf3_factor_blk(lds_f64* D, lds_f64* Dv, lds_f64* stage, int lane, bool store) {
@@ -781,7 +807,7 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     T* Dinv = S + NB * LD;                                  // [8][16][DLD]
     int& fail = *reinterpret_cast<int*>(Dinv + 8 * 16 * DLD);
     int* ecnt = &fail + 1;                                  // waves that have drained their early stores
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches and index arithmetic
     const int fr = lane & 15, fk = lane >> 4;
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T pair_t __attribute__((ext_vector_type(2)));
@@ -886,24 +912,7 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     acc_t x0;                                               // tile 0's X in accumulator layout (every wave's own copy)
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16, r0 = c0 + 16;
-        if (BLK && jb == 0 && wave != 0) {
-            // beside the FIRST factor (nothing else to do yet): the zeros above the diagonal of both output tiles go out, so that the panel /
-            // block-row stores further down only carry what is on or below the diagonal (1152 pairs per step instead of 2048).  (Issued
-            // in the load phase instead they held the tile's way into LDS behind their write acknowledgements: load 2.0 -> 4-5 us.)
-            const pair_t zz = {(T)0, (T)0};
-            for (int idx = tid - 64; idx < NB * NB / 2; idx += NTH - 64) {
-                const int i = idx >> 6, k = (idx & 63) * 2;
-                if (k > i) {
-                    if (WT) st_pair_wt(A, rA, (long)i * lda + k, zz);
-                    else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = zz;
-                    if (inv) {
-                        if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, zz);
-                        else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = zz;
-                    }
-                }
-            }
-        }
-        if (BLK && jb == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's zero stores are out long before any flag is raised
+        if (BLK && jb == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero stores of block rows 0..3 are out before the early flag can be raised
         if (wave < ((BLK && sizeof(T) == 8) ? 1 : NF3)) {
             // ---- F: the diagonal block alone.  lanes 0-15: its rows; lanes 16-31: identity rows, which leave the loop as D^-1.
             // (PG_LEAF3_NF = 2..4: waves 1 .. NF3-1 run the SAME instructions on the same data and store nothing -- an experiment on
@@ -965,7 +974,7 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(r0 + 16 * t + fr) * LD + c0 + Mfma<T>::row(lane, r)] = xt[r];
             }
-        } else if (BLK && jb >= 1) {
+        } else if (BLK && jb >= 1 && jb < SLOT_STORES_FROM) {
             // ---- the waves without a tile (5 + jb of them): what the PREVIOUS step made final goes out -- its sixteen columns of L and
             // block row jb - 1 of the inverse.  (With the row-per-lane factor these stores sat in the slot beside the factor, whose nine
             // workers had time to spare; beside the blocked factor that slot is what the step waits for: tiles 1.3 us + stores 0.6 us
@@ -1010,12 +1019,12 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
                     continue;
                 }
                 if (w < nrest) {
-                    int uu = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
-                    while (uu * (uu + 1) / 2 > w) --uu;
+                    int uu = 0;                                        // w = uu (uu + 1) / 2 + (tj - 1), uu < 6: scalar arithmetic
                     while ((uu + 1) * (uu + 2) / 2 <= w) ++uu;
                     const int ti = uu + 1, tj = w - uu * (uu + 1) / 2 + 1;
-                    lds_tile_mm<T, true>(S + (r0 + ti * 16) * LD + r0 + tj * 16, LD, S + (r0 + ti * 16) * LD + c0, LD,
-                                         S + (r0 + tj * 16) * LD + c0, LD, 16, (T)-1, (T)1, lane);
+                    if (BLK) lds_tile_update16<T>(S + (r0 + ti * 16) * LD + r0 + tj * 16, S + (r0 + ti * 16) * LD + c0, S + (r0 + tj * 16) * LD + c0, lane);
+                    else lds_tile_mm<T, true>(S + (r0 + ti * 16) * LD + r0 + tj * 16, LD, S + (r0 + ti * 16) * LD + c0, LD,
+                                              S + (r0 + tj * 16) * LD + c0, LD, 16, (T)-1, (T)1, lane);
                 } else {
                     inv_tile<T>(S, Dinv, jb, w - nrest, lane);
                     if (last) inv_tile_sum<T>(S, Dinv, jb + 1, w - nrest, lane);
@@ -1027,7 +1036,25 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
             // counts itself in LDS, and the last one raises *early -- the rows of block row k+1 start their solve against
             // those 64 rows while the leaf still has three steps and its tail to run (chainstep.hip).
             if (wstamp) tlog[46] = wall_clock64();
-            if (!BLK && jb >= 1) {
+            if (BLK) {
+                // the zeros above the diagonal of both output tiles, block row jb's share per slot: the panel / block-row stores then only
+                // carry what is on or below the diagonal (1152 pairs per step instead of 2048).  (All of them beside the FIRST factor
+                // took one CU's store path 1.7 us and slowed that factor; in the load phase they held the tile's way into LDS behind
+                // their write acknowledgements: load 2.0 -> 4-5 us.)
+                const pair_t zz = {(T)0, (T)0};
+                for (int idx = 64 * widx + lane; idx < 16 * 64; idx += 64 * nwork) {
+                    const int i = 16 * jb + (idx >> 6), k = (idx & 63) * 2;
+                    if (k > i) {
+                        if (WT) st_pair_wt(A, rA, (long)i * lda + k, zz);
+                        else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = zz;
+                        if (inv) {
+                            if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, zz);
+                            else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = zz;
+                        }
+                    }
+                }
+            }
+            if ((!BLK && jb >= 1) || (BLK && jb >= SLOT_STORES_FROM)) {   // (blocked form: from step 3 on the slot has few tiles left and time to spare)
                 const int t0 = 64 * widx + lane, nth = 64 * nwork;
                 store_l_panel(jb - 1, t0, nth);
                 if (want_inv) store_inv_rows(16 * (jb - 1), 16 * jb, t0, nth);
@@ -1046,6 +1073,20 @@ __device__ __forceinline__ void leaf3_body(char* smem_raw, T* __restrict__ A, lo
     // Panels 0-5 of L and block rows 0-5 of the inverse went out while the loop ran.
     if (want_inv) {
         for (int q = wave; q < 7; q += NWV) inv_tile_finish<T>(S, Dinv, 7, q, lane);
+    }
+    if (BLK) {   // the last block row's zeros above the diagonal (the slots wrote those of block rows 0..6)
+        const pair_t zz = {(T)0, (T)0};
+        for (int idx = tid; idx < 16 * 64; idx += NTH) {
+            const int i = NB - 16 + (idx >> 6), k = (idx & 63) * 2;
+            if (k > i) {
+                if (WT) st_pair_wt(A, rA, (long)i * lda + k, zz);
+                else *reinterpret_cast<pair_t*>(A + (long)i * lda + k) = zz;
+                if (inv) {
+                    if (WT) st_pair_wt(inv, rI, (long)i * ldi + k, zz);
+                    else *reinterpret_cast<pair_t*>(inv + (long)i * ldi + k) = zz;
+                }
+            }
+        }
     }
     store_l_panel(6, tid, NTH);
     store_l_panel(7, tid, NTH);

@@ -505,6 +505,61 @@ def test_potrf_not_positive_definite_reports_minor(ops):
     assert int(info.item()) == 301
 
 
+@pytest.mark.parametrize("j", [0, 1, 3, 4, 7, 8, 12, 15, 16, 21, 63, 127, 128, 133, 255, 300, 511])
+def test_potrf_names_the_first_bad_minor_at_every_position(ops, j):
+    """The leaf factors its 16 x 16 diagonal blocks four columns at a time with the rank-4 updates on the matrix pipe (leaf3_factor_blk):
+    a non-positive pivot in any lane group, panel or block must come back as LAPACK's info = j + 1 (torch.cholesky's message names that
+    minor, gpr.py:69), and a second bad pivot further down must not mask it."""
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(40 + j)
+    n = 512
+    a = spd(n, rng)
+    a[j, j] = -0.5
+    if j + 9 < n:
+        a[j + 9, j + 9] = -2.0
+    _, want = lapack.dpotrf(a, lower=1)
+    assert want == j + 1
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(dev(a), ops.potrf_workspace(n, torch.float64), info)
+    assert int(info.item()) == want
+
+
+def test_leaf_on_badly_scaled_tiles_matches_lapack(ops):
+    """One 128 x 128 leaf (factor + inverse) on a tile whose rows span twelve orders of magnitude and on a tile of condition 1e10: the
+    blocked factor's square-root-free elimination, its staging through LDS and the scaling at the end, against LAPACK and against the
+    backward-error bounds a Cholesky factor and a triangular inverse must meet whatever the conditioning."""
+    rng = np.random.default_rng(77)
+    for kind in ("scaled", "illcond"):
+        if kind == "scaled":
+            q = rng.standard_normal((128, 128))
+            a = q @ q.T / 128 + np.eye(128)
+            sc = 10.0 ** rng.uniform(-6, 6, 128)
+            a = a * sc[:, None] * sc[None, :]
+        else:
+            u, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+            a = (u * np.logspace(0, -10, 128)) @ u.T
+            a = (a + a.T) / 2
+        ad = dev(a)
+        inv = ops.zeros(128, 128)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.leaf_raw(ad, inv, info)
+        assert int(info.item()) == 0
+        chol = np.linalg.cholesky(a)
+        full_l, full_i = host(ad), host(inv)
+        got = np.tril(full_l)
+        dscale = np.sqrt(np.diag(a))
+        # against LAPACK, entry by entry relative to sqrt(a_ii) (|L_ij| <= sqrt(a_ii)): forward error grows with the condition number
+        assert np.abs((got - chol) / dscale[:, None]).max() <= (1e-13 if kind == "scaled" else 1e-6)
+        # L L^T reproduces the tile to working precision relative to its own scale (backward stability)
+        assert np.abs((got @ got.T - a) / np.outer(dscale, dscale)).max() <= 5e-14
+        # the inverse: inv L = I, relative to |inv| |L|
+        gi = np.tril(full_i)
+        res = np.abs(gi @ got - np.eye(128)) / (np.abs(gi) @ np.abs(got))
+        assert res.max() <= 1e-13
+        # the zeros above the diagonal of both tiles are part of the contract (later products treat diagonal tiles as full)
+        assert np.all(np.triu(full_l, 1) == 0) and np.all(np.triu(full_i, 1) == 0)
+
+
 def test_potrf_fp32(ops):
     rng = np.random.default_rng(5)
     n = 512
