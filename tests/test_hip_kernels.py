@@ -554,8 +554,9 @@ def test_leaf_on_badly_scaled_tiles_matches_lapack(ops):
         assert np.abs((got @ got.T - a) / np.outer(dscale, dscale)).max() <= 5e-14
         # the inverse: inv L = I, relative to |inv| |L|
         gi = np.tril(full_i)
-        res = np.abs(gi @ got - np.eye(128)) / (np.abs(gi) @ np.abs(got))
-        assert res.max() <= 1e-13
+        den = np.abs(gi) @ np.abs(got)                       # lower triangular, like the product itself
+        num = np.abs(gi @ got - np.eye(128))
+        assert np.all(num[den == 0] == 0) and (num[den > 0] / den[den > 0]).max() <= 1e-13
         # the zeros above the diagonal of both tiles are part of the contract (later products treat diagonal tiles as full)
         assert np.all(np.triu(full_l, 1) == 0) and np.all(np.triu(full_i, 1) == 0)
 
