@@ -240,6 +240,13 @@ int pg_set_lookahead(pg_handle h, int on);
  * multiple of 128.  The result does not depend on it beyond rounding; a tuning and test knob. */
 int pg_set_outer_panel(pg_handle h, int columns);
 
+/* From min_n points on (default 16384; PG_REC_MIN in the environment at pg_create; 0 = never) the fused pg_potrf_trtri /
+ * pg_build_potrf_trtri splits the matrix at n / 2 and takes the blocks that cross the split as four large products against the
+ * leading half's inverse (csrc/linalg.hip: potrf_trtri_rec; the reference's torch.cholesky + cholesky_solve, gpr.py:69,
+ * loss.py:97-116, has no such knob).  min_n must be 0 or a multiple of 512 >= 512.  The result does not depend on it beyond
+ * rounding; a tuning and test knob (tests run the split at n = 1024). */
+int pg_set_recursive_split(pg_handle h, int min_n);
+
 /* GEMM-core profiling for bench.py's roofline leg: events around every MFMA GEMM launch */
 int pg_profile(pg_handle h, int on);   /* on=1 resets and starts, on=0 stops */
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);

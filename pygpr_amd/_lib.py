@@ -64,6 +64,7 @@ _SIGS = {
     "pg_tril": (_i, [_vp, _i, _i, _vp, _l, _vp]),
     "pg_set_lookahead": (_i, [_vp, _i]),
     "pg_set_outer_panel": (_i, [_vp, _i]),
+    "pg_set_recursive_split": (_i, [_vp, _i]),
     "pg_profile": (_i, [_vp, _i]),
     "pg_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
     "pg_build_potrf_trtri": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _d, _vp, _l, _i, _vp, _vp, _vp, _l, _vp]),

@@ -333,6 +333,10 @@ class HipOps:
     def set_outer_panel(self, columns):
         _lib.check(self.lib.pg_set_outer_panel(self.h, int(columns)), "pg_set_outer_panel")
 
+    def set_recursive_split(self, min_n):
+        """From min_n points on the fused factor-and-invert call splits the matrix recursively (0: never; default 16384)."""
+        _lib.check(self.lib.pg_set_recursive_split(self.h, int(min_n)), "pg_set_recursive_split")
+
     def set_coupled_chain(self, on):
         _lib.check(self.lib.pg_set_coupled_chain(self.h, int(on)), "pg_set_coupled_chain")
 

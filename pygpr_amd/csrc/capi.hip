@@ -221,6 +221,9 @@ int pg_create(pg_handle* h) {
         const char* e = getenv("PG_NBO");
         c->nbo = e ? atoi(e) : 0;
         if (c->nbo < 128 || c->nbo % 128 || c->nbo > 2048) c->nbo = 0;
+        const char* r = getenv("PG_REC_MIN");
+        c->rec_min = r ? atoi(r) : 16384;
+        if (c->rec_min < 0 || (c->rec_min > 0 && (c->rec_min < 512 || c->rec_min % 512))) c->rec_min = 16384;
         const char* v = getenv("PG_PANEL_MODE");
         c->panel_mode = v ? atoi(v) : 0;
     }
@@ -236,6 +239,7 @@ int pg_create(pg_handle* h) {
         const char* env = getenv("PG_RESERVED_CUS");
         int reserved = env ? atoi(env) : PG_RESERVED_CUS;
         if (reserved < 1 || reserved > ncu / 2) reserved = PG_RESERVED_CUS;
+        c->ncu = ncu; c->upd_cus = ncu - reserved;
         for (int cu = 0; cu < ncu - reserved; ++cu) mask[cu / 32] |= (1u << (cu % 32));   // (a strided reservation was measured: 9 % slower)
         if (ncu <= reserved * 2 || words > 64 ||
             hipExtStreamCreateWithCUMask(&c->upd, (uint32_t)words, mask) != hipSuccess) {
@@ -657,6 +661,13 @@ int pg_set_outer_panel(pg_handle h, int columns) {
     NEED(h, "null handle");
     NEED(columns == 0 || (columns >= 128 && columns % 128 == 0 && columns <= 2048), "outer panel must be 0 (automatic) or a multiple of 128 up to 2048");
     h->nbo = columns;
+    return 0;
+}
+
+int pg_set_recursive_split(pg_handle h, int min_n) {
+    NEED(h, "null handle");
+    NEED(min_n == 0 || (min_n >= 512 && min_n % 512 == 0), "min_n must be 0 (never) or a multiple of 512");
+    h->rec_min = min_n;
     return 0;
 }
 

@@ -25,6 +25,7 @@ struct pg_ctx {
     int npool;
     int lookahead;            // 0 disables the two-stream Cholesky (default 1)
     int nbo;                  // outer panel of the Cholesky; 0 = chosen from n (pg_set_outer_panel / PG_NBO)
+    int rec_min;              // the fused factor-and-invert call splits recursively from this n on (pg_set_recursive_split / PG_REC_MIN; 0: never)
     int coupled;              // the flag-coupled chain may be used (pg_set_coupled_chain; cleared by pg_create when kernels of the
                               // panel and rows streams do not run concurrently here, e.g. under a counter-collecting profiler)
     int last_coupled;         // panels the last factorisation ran on the flag-coupled chain (chainstep.hip); tests / diagnostics
@@ -38,6 +39,7 @@ struct pg_ctx {
     int chain_epoch;          // counts the factorisations that took the coupled chain; an expiry reports its call's number
     int counted_epoch;        // the last epoch whose time-out was counted
     int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory
+    int ncu, upd_cus;         // compute units of the device / those the update stream's mask leaves it (workgroup slots of a launch: 2 per CU)
     int prof_on;              // profiling of the GEMM core (bench roofline leg)
     double prof_flops;
     double prof_ms;

@@ -69,38 +69,9 @@ template <typename T, int R, bool KCONT, int BKT = BK, int NTH = 256> struct Sta
     }
 };
 
-template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP<T> p) {
-    constexpr int NTH = 64 * NW;
-    typedef Stage<T, BM, !TA, BKT, NTH> SA;   // A: K-contiguous when not transposed
-    typedef Stage<T, BN, TB, BKT, NTH> SB;    // B: K-contiguous when transposed
-    typedef typename Mfma<T>::acc_t acc_t;
-    // wave tile; 4 waves cover BM x BN: 128x128 -> 64x64, 64x256 -> 64x64, 64x64 -> 32x32, 64x128 -> 32x64,
-    // 32x64 -> 16x32, 32x128 -> 32x32, 32x32 -> 16x16
-    // (NW == 8: eight waves of 64 x 32 on the 128 x 128 block -- half the accumulators per wave, twice the waves per SIMD)
-    constexpr int WTM = (BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN <= 64) ? 16 : 32);
-    constexpr int WTN = (NW == 8) ? 32 : ((BN == 32) ? 16 : ((BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64));
-    constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
-    constexpr int WN_ = BN / WTN;                             // waves along N
-    static_assert((BM / WTM) * (BN / WTN) == NW, "the waves must tile the block");
-
-    const int ze = (int)blockIdx.y / p.batch;                      // which of the batched problems (experts)
-    if (p.info && p.info[(long)ze * p.einfo] != 0) return;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* As = reinterpret_cast<T*>(smem_raw);
-    T* Bs = As + 2 * SA::LDS_ELEMS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN_, wn = wave % WN_;
-
-    // XCD-aware tile order: blocks b, b+8, .. share one XCD's L2; give each XCD a contiguous run of
-    // tiles (bijective for any grid size) so neighbouring tiles re-use operand panels from L2.
-    // Tiles with unequal K ranges (triangular operands) keep launch order instead: longest first and
-    // round-robin over the XCDs, which balances the work.
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
-    const int wg = (p.klo | p.khi | p.noxcd) ? b : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-
+// Tile -> (ti, tj) for enumeration index wg of a launch with `nwg` tiles in this order (see the comments inside).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_decode(const GemmP<T>& p, int wg, int& ti, int& tj) {
     // Equal-work launches walk the tiles in bands of GR tile rows, column by column inside a band: the 64 tiles an XCD
     // has in flight then form an 8 x 8 patch that re-uses 8 A panels and 8 B panels from its L2 (a row-major walk
     // re-uses one A panel and misses on every B panel; PMC: -10 % L2 fetch over an evaluation).  Launches with K ranges
@@ -108,7 +79,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
     // of different rows do not, and patches made of them fetched MORE (measured: lauum 59 -> 80 GB, 8 % slower).
     constexpr int GR = 8;
     const bool grouped = !(p.klo | p.khi | p.noxcd);
-    int ti, tj;
     if (p.tri && grouped) {
         // band g = tile rows [8g, 8g+8): 64 g + 36 tiles, the bands before it hold 32 g (g - 1) + 36 g
         int g = (int)((sqrtf(1024.0f + 128.0f * (float)wg) - 32.0f) / 64.0f);
@@ -139,12 +109,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
         const int rows = min(GR, tmr - r0), w = wg - band * GR * tn;
         ti = r0 + w % rows;
         tj = w / rows;
+    } else if (p.khi == 2 && p.N / BN > 1) {
+        // K grows with the tile COLUMN (a product against a lower-triangular B^T): column-major, the long columns first -- the tiles
+        // of a column share their K range and B panel and stay in lockstep, and the launch does not end on its longest tiles
+        const int tmr = p.M / BM;
+        tj = p.N / BN - 1 - wg / tmr;
+        ti = wg % tmr;
     } else {
         const int tn = p.N / BN;
         ti = wg / tn;
         tj = wg % tn;
         if (p.khi == 1) ti = p.M / BM - 1 - ti;   // K grows with the tile row: launch the long rows first
     }
+}
+
+// XCD-aware tile order: blocks b, b+8, .. share one XCD's L2; give each XCD a contiguous run of
+// tiles (bijective for any grid size) so neighbouring tiles re-use operand panels from L2.
+// Tiles with unequal K ranges (triangular operands) keep launch order instead: longest first and
+// round-robin over the XCDs, which balances the work.
+template <typename T> __device__ __forceinline__ int gemm_xcd_order(const GemmP<T>& p, int b, int nwg) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = b & 7;
+    return (p.klo | p.khi | p.noxcd) ? b : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT, int NW>
+__device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, char* smem_raw) {
+    constexpr int NTH = 64 * NW;
+    typedef Stage<T, BM, !TA, BKT, NTH> SA;   // A: K-contiguous when not transposed
+    typedef Stage<T, BN, TB, BKT, NTH> SB;    // B: K-contiguous when transposed
+    typedef typename Mfma<T>::acc_t acc_t;
+    // wave tile; 4 waves cover BM x BN: 128x128 -> 64x64, 64x256 -> 64x64, 64x64 -> 32x32, 64x128 -> 32x64,
+    // 32x64 -> 16x32, 32x128 -> 32x32, 32x32 -> 16x16
+    // (NW == 8: eight waves of 64 x 32 on the 128 x 128 block -- half the accumulators per wave, twice the waves per SIMD;
+    //  eight waves of 16 x 32 on a 64 x 64 block: the quarter tiles that end a mixed launch, pg_gemm_mixed_kernel)
+    constexpr int WTM = (NW == 8 && BM == 64) ? 16 : ((BM == 128 || BN == 256) ? 64 : ((BM == 32 && BN <= 64) ? 16 : 32));
+    constexpr int WTN = (NW == 8) ? 32 : ((BN == 32) ? 16 : ((BN == 64 || (BM == 32 && BN == 128)) ? 32 : 64));
+    constexpr int MIM = WTM / 16, MIN = WTN / 16;             // MFMA tiles per wave tile
+    constexpr int WN_ = BN / WTN;                             // waves along N
+    static_assert((BM / WTM) * (BN / WTN) == NW, "the waves must tile the block");
+    const int ze = (int)blockIdx.y / p.batch;                      // which of the batched problems (experts)
+    T* As = reinterpret_cast<T*>(smem_raw);
+    T* Bs = As + 2 * SA::LDS_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN_, wn = wave % WN_;
     const long zb = (int)blockIdx.y % p.batch;
     const T* __restrict__ A = p.A + zb * p.sA + ze * p.eA;
     const T* __restrict__ B = p.B + zb * p.sB + ze * p.eB;
@@ -253,6 +261,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP
 }
 
 template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void pg_gemm_kernel(GemmP<T> p) {
+    const int ze = (int)blockIdx.y / p.batch;                      // which of the batched problems (experts)
+    if (p.info && p.info[(long)ze * p.einfo] != 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int ti, tj;
+    gemm_decode<T, BM, BN>(p, gemm_xcd_order(p, blockIdx.x, gridDim.x), ti, tj);
+    gemm_tile<T, TA, TB, BM, BN, EPI, BKT, NW>(p, ti, tj, smem_raw);
+}
+
+// Mixed launch (round 4): the first `tmain` tiles as 128 x 128 blocks, the REST as 64 x 64 quarter tiles of the same eight-wave
+// workgroups.  A launch of equally long tiles on S workgroup slots takes ceil(tiles / S) rounds -- the lower tiles of an
+// h = 8192, K = 8192 update are 2080 = 4.06 rounds and took five (8.9 ms against 7.75 for 2016 tiles, tools/probe_tri_rounds.py);
+// with tmain = a whole number of rounds the remainder ends in quarter-length tiles instead.  One workgroup per output element as
+// before: same numbers bit for bit (the k order of an element does not depend on the tile shape).
+template <typename T>
+__global__ __launch_bounds__(512, 4) void pg_gemm_mixed_kernel(GemmP<T> p, int tmain) {
+    if (p.info && p.info[0] != 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = blockIdx.x;
+    int ti, tj;
+    if (b < tmain) {
+        gemm_decode<T, 128, 128>(p, gemm_xcd_order(p, b, tmain), ti, tj);
+        gemm_tile<T, false, true, 128, 128, 0, BK, 8>(p, ti, tj, smem_raw);
+    } else {
+        const int s = b - tmain, q = s & 3;
+        gemm_decode<T, 128, 128>(p, tmain + (s >> 2), ti, tj);
+        if (p.tri && ti == tj && q == 1) return;               // the quarter above the diagonal
+        // a 32-deep K tile: one such workgroup per CU is bound by the latency of its one-tile-ahead prefetch, not by its MFMAs
+        // (16-deep: 1.0 ms per quarter tile at K = 8192, the length of a FULL tile's 0.45 ms share twice over)
+        gemm_tile<T, false, true, 64, 64, 0, 32, 8>(p, 2 * ti + (q >> 1), 2 * tj + (q & 1), smem_raw);
+    }
+}
+
+template <typename T, bool TA, bool TB, int BM, int BN, int EPI, int BKT = BK, int NW = 4>
 static int launch(hipStream_t st, const GemmP<T>& p) {
     typedef Stage<T, BM, !TA, BKT, 64 * NW> SA;
     typedef Stage<T, BN, TB, BKT, 64 * NW> SB;
@@ -277,6 +319,24 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
     return 0;
 }
 
+template <typename T> static int launch_mixed(hipStream_t st, const GemmP<T>& p, int tmain) {
+    typedef Stage<T, 128, true, BK, 512> S128;
+    typedef Stage<T, 64, true, 32, 512> S64;
+    static_assert(S64::LDS_ELEMS <= S128::LDS_ELEMS, "the quarter tiles' stages must fit the block's LDS");
+    const size_t lds = 4 * S128::LDS_ELEMS * sizeof(T);
+    static bool attr_done = false;
+    auto kern = pg_gemm_mixed_kernel<T>;
+    if (!attr_done) {
+        PG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const long tm = p.M / 128, tn = p.N / 128, tiles = p.tri ? tm * (tm + 1) / 2 : tm * tn;
+    dim3 grid((unsigned)(tmain + 4 * (tiles - tmain)), 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p, tmain);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}
+
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
     const int BM = (variant == GEMM_NT_32x64 || variant == GEMM_NT_32x128 || variant == GEMM_NT_32x32) ? 32
                    : ((variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_TT_64) ? 64 : 128);
@@ -297,7 +357,8 @@ double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi
     return f * batch;
 }
 
-template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, const GemmP<T>& p_in) {
+template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant_in, const GemmP<T>& p_in) {
+    int variant = variant_in;
     static const int noxcd = getenv("PG_NOXCD") ? atoi(getenv("PG_NOXCD")) : 0;
     // 128 x 128 blocks: eight waves of 64 x 32 (default) or the round-1 form, four waves of 64 x 64 (PG_GEMM_W4=1).  Same
     // numbers bit for bit; four waves per SIMD instead of two cover the staging and barrier stalls: uniform 8192^3 69.1 ->
@@ -314,7 +375,23 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
     const bool prof = ctx && ctx->prof_on;
     if (prof) PG_CHECK(hipEventRecord(ctx->ev[6], st));
     int rc;
+    // equally long 128 x 128 tiles that do not fill a whole number of rounds of the stream's workgroup slots: mixed launch
+    static const int mixed_env = getenv("PG_GEMM_MIXED") ? atoi(getenv("PG_GEMM_MIXED")) : 1;
+    if (mixed_env && variant == GEMM_NT_128 && !w4 && sizeof(T) == 8 && ctx && ctx->ncu > 0 && !p.klo && !p.khi && !p.noxcd && p.batch == 1 &&
+        p.nexp == 1 && p.part == nullptr && p.M % 128 == 0 && p.N % 128 == 0 && p.K % 32 == 0 && (!p.tri || p.M == p.N)) {
+        const long tm = p.M / 128, tn = p.N / 128, tiles = p.tri ? tm * (tm + 1) / 2 : tm * tn;
+        const long slots = 2L * ((ctx->upd && st == ctx->upd) ? ctx->upd_cus : ctx->ncu);
+        const long rem = tiles % slots;
+        // quarter tiles run at about 0.3 of a full tile's length each: worth it while four times the remainder stays within ~2.5 rounds
+        if (tiles > slots && rem > 0 && 4 * rem <= (5 * slots) / 2) {
+            if constexpr (sizeof(T) == 8) {
+                if ((rc = launch_mixed<T>(st, p, (int)(tiles - rem)))) return rc;
+                variant = -1;
+            }
+        }
+    }
     switch (variant) {
+        case -1: rc = 0; break;
         case GEMM_NT_128: rc = w4 ? launch<T, false, true, 128, 128, 0>(st, p) : launch<T, false, true, 128, 128, 0, BK, 8>(st, p); break;
         case GEMM_NT_RP: rc = launch<T, false, true, 64, 256, 0>(st, p); break;
         case GEMM_NN_128: rc = w4 ? launch<T, false, false, 128, 128, 0>(st, p) : launch<T, false, false, 128, 128, 0, BK, 8>(st, p); break;
@@ -333,6 +410,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant, cons
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }
     if (rc) return rc;
+    variant = variant_in;
     {   // PG_GEMM_LOG=<file>: one line per launch (variant, waves, shape, flops) in launch order, for tools/trace_util.py
         static FILE* logf = getenv("PG_GEMM_LOG") ? fopen(getenv("PG_GEMM_LOG"), "w") : nullptr;
         if (logf) {

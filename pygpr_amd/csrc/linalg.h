@@ -21,7 +21,8 @@ struct ExpBatch {
 };
 template <typename T>
 int pg_potrf_t(pg_ctx*, hipStream_t, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build = nullptr,
-               const ExpBatch* eb = nullptr);
+               const ExpBatch* eb = nullptr, int col_off = 0, int keep_info = 0);   // col_off: added to the column a bad pivot reports (a call on a
+                                                                                     // trailing block); keep_info: do not reset *info (it continues a call)
 template <typename T> int pg_potrs_vec_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, const T* y, T* x, T* work);
 template <typename T>
 int pg_trtri_t(pg_ctx*, hipStream_t, int n, const T* L, long ldl, const T* invD, T* M, long ldm, int hmax = 0, const ExpBatch* eb = nullptr);

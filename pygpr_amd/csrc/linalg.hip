@@ -482,6 +482,82 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
     return 0;
 }
 
+template <typename T>
+int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build,
+               const ExpBatch* eb, int col_off, int keep_info);
+
+// Recursive top level of the fused factor-and-invert call (round 4).  For n >= ctx->rec_min (pg_set_recursive_split / PG_REC_MIN,
+// default 16384: at 12288 the one-level schedule is 0.5 ms faster, at 20480 / 24576 this one by 1.2 / 2.1 ms) the matrix is split at
+// h1 = n/2 (rounded to the padding unit) and everything that crosses the split is ONE large product of the GEMM core:
+//     [L11, M11] = potrf_trtri(A11)                     (this function again; the coupled chain below 8192 rows)
+//     L21 = K21 M11^T                                   (the panel "solve" as a product with the inverse we need anyway; K ranges)
+//     A22 -= L21 L21^T                                  (ONE update with K = h1 instead of h1 / 1024 updates beside the chain)
+//     [L22, M22] = potrf_trtri(A22)
+//     M21 = -M22 (L21 M11)                              (the top level of the triangular inverse, as before)
+// The same 2 n^3 / 3 flop as pg_potrf + pg_trtri, but the n^3 / 2 that cross the split run as four full-chip products at the core's
+// own rate (K = h1 deep, no chain beside them) instead of h1 / 1024 right-looking updates that share the chip with the chain's short
+// kernels (52 TFLOP/s in the update-bound phase against 66-69 for these products).  No extra memory: K21 is built (or copied) into
+// the M21 block of the inverse's buffer -- free until the last product writes it -- so the panel product is out of place.
+// A bad pivot in the leading half leaves info != 0: every later launch returns at once (GemmP::info), the second half keeps it.
+static int pg_rec_split(const pg_ctx* ctx, int n) {
+    if (ctx->rec_min <= 0 || n < ctx->rec_min || n < 2 * PG_PAD || ctx->bg || ctx->panel_mode) return 0;
+    return ((n / 2 + PG_PAD - 1) / PG_PAD) * PG_PAD;
+}
+
+template <typename T>
+static int potrf_trtri_rec(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm,
+                           const BuildReq<T>* build, int col_off) {
+    const int h1 = pg_rec_split(ctx, n), h2 = n - h1;
+    int rc;
+    T* A21 = A + (long)h1 * lda;
+    T* A22 = A21 + h1;
+    T* M21 = Minv + (long)h1 * ldm;
+    BuildReq<T> b1;
+    if (build) { b1 = *build; b1.n_real = std::min(build->n_real, h1); }
+    const bool side = build && ctx->lookahead && !ctx->prof_on && ctx->upd;
+    if (side) PG_CHECK(hipEventRecord(ctx->ev[0], st));     // this call's start: what the trailing blocks' build has to wait for
+    if ((rc = pg_potrf_t<T>(ctx, st, h1, A, lda, invD, info, Minv, ldm, build ? &b1 : nullptr, nullptr, col_off, 1))) return rc;
+    if (build) {
+        const int nr2 = std::max(0, build->n_real - h1);
+        const T* X2 = build->X + (long)h1 * build->ldx;
+        // K21 -> the M21 block (cross build: no noise, no jitter), K22 -> A22 (lower tiles).  On the update stream, behind the leading
+        // half's last trailing update: HBM-bound work beside that factorisation's chain-bound tail and the MFMA-bound inverse.
+        hipStream_t bs = side ? ctx->upd : st;
+        if (side) PG_CHECK(hipStreamWaitEvent(bs, ctx->ev[0], 0));   // the blocks' previous readers ran on st before this call
+        if ((rc = pg_kbuild<T>(bs, *build->spec, build->hp, X2, build->ldx, nr2, build->X, build->ldx, std::min(build->n_real, h1), build->d,
+                               0, 0, 0, 0.0, M21, ldm, h2, h1)))
+            return rc;
+        if ((rc = pg_kbuild<T>(bs, *build->spec, build->hp, X2, build->ldx, nr2, X2, build->ldx, nr2, build->d, 1, 1, 0, build->jitter, A22,
+                               lda, h2, h2)))
+            return rc;
+        if (side) {
+            PG_CHECK(hipEventRecord(ctx->ev[1], bs));
+            PG_CHECK(hipStreamWaitEvent(st, ctx->ev[1], 0));
+        }
+    } else {
+        const long vecs = (long)h2 * h1 / (16 / sizeof(T));
+        hipLaunchKernelGGL(copy_rows_kernel<T>, dim3((unsigned)std::min<long>((vecs + 255) / 256, 8192)), dim3(256), 0, st, A21, lda, M21, ldm,
+                           h2, h1);
+        LAUNCH_CHECK();
+    }
+    {   // L21 = K21 M11^T: M11 is lower triangular, tile column j needs k < (j + 1) 128
+        GemmP<T> p = gp0<T>(); p.info = info;
+        p.M = h2; p.N = h1; p.K = h1; p.A = M21; p.lda = ldm; p.B = Minv; p.ldb = ldm; p.C = A21; p.ldc = lda; p.khi = 2;
+        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+    }
+    {   // A22 -= L21 L21^T: 2080 equally long lower tiles at n = 16384 -- 4.06 rounds of the chip's 512 workgroup slots; pg_gemm ends such
+        // a launch in quarter tiles (pg_gemm_mixed_kernel: 8.9 -> 8.0 ms)
+        GemmP<T> p = gp0<T>(); p.info = info;
+        p.M = p.N = h2; p.K = h1; p.A = A21; p.lda = lda; p.B = A21; p.ldb = lda; p.C = A22; p.ldc = lda;
+        p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
+        if ((rc = pg_gemm<T>(ctx, st, GEMM_NT_128, p))) return rc;
+    }
+    if ((rc = pg_potrf_t<T>(ctx, st, h2, A22, lda, invD + (long)(h1 / NB) * NB * NB, info, Minv + (long)h1 * ldm + h1, ldm, nullptr, nullptr,
+                            col_off + h1, 1)))
+        return rc;
+    return trtri_top<T>(ctx, st, h1, h2, A, lda, Minv, ldm, true, true);
+}
+
 // Look-ahead: for outer panel o let Chain(o) = its 8 (U, leaf, T) steps, Sa(o) = update of panel o+1's columns by
 // panel o (all rows below), Sb(o) = lower-tile SYRK of everything right of panel o+1 by panel o.
 //   panel stream  (handle's high-priority stream)       : Chain(0) Sa(0) Chain(1) [wait Sb(0)] Sa(1) Chain(2) [wait Sb(1)] Sa(2) ...
@@ -493,13 +569,14 @@ static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
 // the caller's stream at the end.
 template <typename T>
 int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int* info, T* Minv, long ldm, const BuildReq<T>* build,
-               const ExpBatch* eb) {
+               const ExpBatch* eb, int col_off, int keep_info) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_potrf: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     const int nexp = eb ? eb->nexp : 1;                       // batched experts: every launch below covers all of them
     const long eA = eb ? eb->eA : 0, eI = eb ? eb->eInv : 0;
     if (nexp < 1) { pg_set_error("pg_potrf: empty batch"); return -2; }
     auto batched = [&](GemmP<T>& p, long sa, long sb, long sc) { p.nexp = nexp; p.eA = sa; p.eB = sb; p.eC = sc; p.einfo = nexp > 1 ? 1 : 0; };
-    PG_CHECK(hipMemsetAsync(info, 0, sizeof(int) * nexp, st));
+    if (!keep_info) PG_CHECK(hipMemsetAsync(info, 0, sizeof(int) * nexp, st));
+    if (Minv && nexp == 1 && pg_rec_split(ctx, n) > 0) return potrf_trtri_rec<T>(ctx, st, n, A, lda, invD, info, Minv, ldm, build, col_off);
     const int NBO = pg_nbo(ctx, n);
     // Outer panel boundaries (uniform; the last one may be short).  Measured on the round-2 build and left out: cutting the
     // first panel in two (256 + NBO - 256 columns) so that the first big update starts after two leaves instead of eight,
@@ -595,6 +672,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // (n = 8192, steps 8-10: 34 | 158 | 228 us, the leaf of the next panel not even finding a CU for 190 us).
     static const int sa_rows = getenv("PG_CS_SA_ROWS") ? atoi(getenv("PG_CS_SA_ROWS")) : 0;   // measured: slower at every setting (n = 8192: off 4.77, 6144: 4.83, 4608: 4.90, 3072: 4.98, 2048: 5.06 ms): the panel period there is the trailing update's own time
     auto sa_after = [&](int o) { return sa_rows > 0 && o >= o_s && o + 1 < npan && (n - pb[o + 1]) > sa_rows; };
+    std::vector<char> nf_split(npan + 1, 0);   // Sb(o) was launched as NEAR + FAR
     for (int o = 0; o < npan; ++o) {
         const int o0 = pb[o], oend = pb[o + 1];
         const bool cp = o >= o_s;
@@ -611,7 +689,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             for (int k0 = o0; k0 < oend; k0 += NB) {
                 const int kb = k0 / NB;
                 T* inv = invD + (long)kb * NB * NB;
-                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw,
+                if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0 + col_off, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw,
                                           two_phase ? f_early + kb : nullptr)))
                     return rc;
                 if (n - k0 - NB <= 0) break;
@@ -621,7 +699,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 const int wstart = (oc == o_s || (oc == o && sa_prev)) ? pb[oc] : pb[oc - 1];
                 const bool last_sa = c == oend && sa_this;   // the next panel's first column is Sa(o)'s: this step only solves
                 if (c == oend && oc >= 2 && !last_sa) {      // first touch of panel oc: Sb(oc - 2) wrote these columns last
-                    if ((rc = pool_event(ctx, 2 + 2 * (oc - 2) + 1, &ev))) return rc;
+                    // (its NEAR launch when that panel was a coupled one: nf_split[oc - 2])
+                    if ((rc = pool_event(ctx, nf_split[oc - 2] ? 9 + 3 * npan + (oc - 2) : 2 + 2 * (oc - 2) + 1, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
                 if (c == oend && oc == 1 && build_split && !last_sa) {   // first touch of a column the folded build wrote on the update stream
@@ -660,7 +739,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 if (nexp > 1 && buv == 2 && (long)(p.M / 64) * 2 * nexp >= 256) uv = GEMM_NT_64;
                 if ((rc = pg_gemm<T>(ctx, ps, uv, p))) return rc;
             }
-            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0, 0, nexp, eA, eI))) return rc;
+            if ((rc = pg_leaf<T>(ps, Akk, lda, inv, NB, info, k0 + col_off, 0, nexp, eA, eI))) return rc;
             const int m = tri_end - k0 - NB;
             if (m > 0) {     // T: rows below <- rows below * inv(L_kk)^T (in place: one workgroup owns 64 full rows)
                 GemmP<T> p = gp0<T>(); p.info = info;
@@ -739,7 +818,32 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             if ((rc = pg_gemm<T>(ctx, la ? cs : us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         }
         const int m2 = n - o2;
-        if (m2 > 0) {  // Sb(o)
+        // Coupled panels (round 4): Sb(o) in two launches, NEAR = panel o+2's columns (all rows below), then FAR = everything right of
+        // them.  The last rows kernel of Chain(o + 1) touches panel o+2's first column and so had to wait for ALL of Sb(o), while
+        // Sb(o + 1) waits for that chain: the update stream idled 58-60 us per panel (profiles/r03_potrf_kernel_trace_n8192.txt).
+        // Now that rows kernel waits for NEAR(o) only, Chain(o + 1) ends beside FAR(o), and NEAR(o + 1) queues right behind it.
+        static const int nf_env = getenv("PG_CS_NEARFAR") ? atoi(getenv("PG_CS_NEARFAR")) : 1;
+        const int o3 = (o + 3 <= npan) ? pb[o + 3] : n;
+        const bool near_far = cp && nf_env && la && m2 > 0 && o3 < n;
+        if (near_far) {
+            nf_split[o] = 1;
+            GemmP<T> p = gp0<T>(); p.info = info;
+            p.M = n - o2; p.N = o3 - o2; p.K = oend - o0;
+            p.A = A + (long)o2 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o2 * lda + o2; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1;
+            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            if ((rc = pool_event(ctx, 9 + 3 * npan + o, &ev))) return rc;   // ev_near[o]
+            PG_CHECK(hipEventRecord(ev, us));
+            T* P = A + (long)o3 * lda + o0;
+            p = gp0<T>(); p.info = info;
+            p.M = p.N = n - o3; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
+            p.C = A + (long)o3 * lda + o3; p.ldc = lda;
+            p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
+            const long ftiles = (long)(p.M / 128) * (p.M / 128 + 1) / 2;
+            static const long sb_thresh2 = getenv("PG_SB_TILE_THRESH") ? atol(getenv("PG_SB_TILE_THRESH")) : 2048;
+            if ((rc = pg_gemm<T>(ctx, us, ftiles < sb_thresh2 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+        } else if (m2 > 0) {  // Sb(o)
             T* P = A + (long)o2 * lda + o0;
             GemmP<T> p = gp0<T>(); p.info = info;
             p.M = p.N = m2; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
@@ -1064,7 +1168,7 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
 }
 
 #define INST(T)                                                                                                        \
-    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*, const ExpBatch*); \
+    template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*, const ExpBatch*, int, int); \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int, const ExpBatch*);       \
     template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \

@@ -432,6 +432,95 @@ def test_potrf_trtri_fused_matches_separate(ops, n):
     assert float((l1 @ (l1.T @ v) - a @ v).abs().max()) <= 1e-9 * float((a @ v).abs().max())   # L L^T = A
 
 
+@pytest.mark.parametrize("n,with_build,dtype", [(1024, False, torch.float64), (1536, True, torch.float64), (2560, False, torch.float64),
+                                                 (2048, True, torch.float32)])
+def test_recursive_split_matches_one_level_schedule(ops, n, with_build, dtype):
+    """Round 4: from pg_set_recursive_split's size on (default 16384) the fused factor-and-invert call splits the matrix at n / 2 and
+    computes the blocks that cross the split as products against the leading half's inverse (linalg.hip: potrf_trtri_rec).  Forced
+    at small sizes (1024: one level; 1536: halves of 768; 2560: TWO levels, 1280 -> 768 + 512; fp32), with a caller-supplied matrix
+    (the off-diagonal block is copied into the inverse's buffer) and with the folded covariance build (it is built there): factor and
+    inverse against the one-level schedule of the same library and against LAPACK."""
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(n)
+    tol = 1e-11 if dtype == torch.float64 else 2e-3
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = []
+    try:
+        for rec in (512, 0):
+            ops.set_recursive_split(rec)
+            a, m = ops.empty(n, n, dtype=dtype), ops.zeros(n, n, dtype=dtype)
+            invd = ops.potrf_workspace(n, dtype)
+            if with_build:
+                d = 3
+                x = np.random.default_rng(7).random((n - 37, d))         # 37 rows of identity padding in the trailing block
+                hp = np.array([1.1, 0.8, 0.9, 1.2, 0.3])
+                ops.build_factor(_spec([orc.SE, orc.WN], d), dev(hp), dev(x, dtype), a, invd, info, m)
+                k = orc.kernel([orc.SE, orc.WN], hp, x) + 1e-7 * np.eye(n - 37)
+                ref = np.eye(n)
+                ref[:n - 37, :n - 37] = k
+            else:
+                ref = spd(n, rng) if rec else ref
+                a.copy_(dev(ref, dtype))
+                ops.potrf_trtri(a, invd, info, m)
+            assert int(info.item()) == 0
+            res.append((np.tril(host(a)), np.tril(host(m))))
+        (l_rec, m_rec), (l_one, m_one) = res
+        want, _ = lapack.dpotrf(ref, lower=1)
+        np.testing.assert_allclose(l_rec, np.tril(want), atol=tol)
+        np.testing.assert_allclose(l_rec, l_one, atol=tol)
+        np.testing.assert_allclose(m_rec, m_one, atol=tol * 10 * np.abs(m_one).max())
+        np.testing.assert_allclose(m_rec @ l_rec, np.eye(n), atol=tol * 100)
+    finally:
+        ops.set_recursive_split(16384)
+
+
+@pytest.mark.parametrize("j", [5, 300, 511, 512, 700, 1023])
+def test_recursive_split_names_the_first_bad_minor(ops, j):
+    """A non-positive pivot in the leading half (later launches return at once, the trailing half must not reset the flag), on the
+    split, and in the trailing half (the leaf's column + the block's offset): LAPACK's info = j + 1 either way."""
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(90 + j)
+    n = 1024
+    a = spd(n, rng)
+    a[j, j] = -0.5
+    _, want = lapack.dpotrf(a, lower=1)
+    assert want == j + 1
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    try:
+        ops.set_recursive_split(512)
+        ops.potrf_trtri(dev(a), ops.potrf_workspace(n, torch.float64), info, ops.empty(n, n))
+        assert int(info.item()) == want
+    finally:
+        ops.set_recursive_split(16384)
+
+
+@pytest.mark.parametrize("t,tri", [(33, 1), (24, 0), (46, 1)])
+def test_gemm_mixed_launch_is_bit_identical(ops, t, tri):
+    """Round 4: a launch of equally long 128 x 128 tiles that does not fill a whole number of rounds of the chip's workgroup slots ends in
+    64 x 64 quarter tiles (pg_gemm_mixed_kernel; 561 / 576 / 1081 tiles here: 49, 64 and 57 past a round of 512).  Every output element is
+    still one workgroup's sum over k in the same order: against the same product through 128-tile launches that are NOT mixed
+    (row slabs of at most 512 tiles), bit for bit; and against NumPy."""
+    from pygpr_amd._lib import GEMM_NT
+
+    g = torch.Generator(device="cuda").manual_seed(t)
+    n, k = 128 * t, 256
+    a = torch.randn(n, k, device="cuda", dtype=torch.float64, generator=g)
+    c0 = torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g)
+    c1, c2 = c0.clone(), c0.clone()
+    ops.gemm_raw(GEMM_NT, n, n, k, -1.0, a, a, 1.0, c1, tri=tri)
+    rows = 128 * (512 // t)                                   # slabs of fewer than 512 tiles: never mixed
+    for r0 in range(0, n, rows):
+        r1 = min(n, r0 + rows)
+        ops.gemm_raw(GEMM_NT, r1 - r0, n, k, -1.0, a[r0:r1], a, 1.0, c2[r0:r1])
+    m1, m2 = (torch.tril(c1), torch.tril(c2)) if tri else (c1, c2)
+    assert torch.equal(m1, m2)
+    ref = host(c0) - host(a) @ host(a).T
+    np.testing.assert_allclose(host(m1), np.tril(ref) if tri else ref, atol=1e-11)
+    if tri:     # tiles strictly above the diagonal are not touched
+        i, jj = 0, n - 128
+        assert torch.equal(c1[i:i + 128, jj:jj + 128], c0[i:i + 128, jj:jj + 128])
+
+
 @pytest.mark.parametrize("n", [1792, 2304, 3072, 4864])
 def test_potrs_vec_blocked_sweeps(ops, n):
     """x = A^-1 y from the factor.  Below n = 2048 one fused step per 128 columns; above, sweeps over 1024-wide blocks

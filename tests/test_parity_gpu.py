@@ -471,8 +471,8 @@ def test_large_d_through_the_class_surface():
 def test_headline_size_properties():
     """BASELINE config 3's size, N=16384 D=8 fp64 -- the schedule bench.py times (1024-column outer panels, the last 8192 rows
     on the flag-coupled chain): (i) directional derivative against central differences, (ii) K alpha = y through a
-    prediction at training inputs, (iii) the fused pg_potrf_trtri factor equals the separate pg_potrf bit for bit and
-    its inverse undoes it."""
+    prediction at training inputs, (iii) the fused pg_potrf_trtri factor equals the separate pg_potrf (to rounding: the fused call
+    takes the recursive split at this size) and its inverse undoes it."""
     from pygpr_amd._ops import get_ops
 
     n, d = 16384, 8
@@ -506,8 +506,17 @@ def test_headline_size_properties():
     ops.potrf_trtri(a, invd, info, minv)
     assert int(info.item()) == 0
     ops.potrf(b, invd2, info)
-    assert torch.equal(torch.tril(a), torch.tril(b))
-    del b
+    # Round 4: from n = 16384 the fused call splits the matrix at n / 2 and takes everything that crosses the split as four large
+    # products (linalg.hip: potrf_trtri_rec), so its factor equals pg_potrf's to rounding, not bit for bit (measured 2e-13 on
+    # entries of size <= 1.1); PG_REC_MIN=0 restores the one-level schedule and the bitwise equality.
+    fa, fb = torch.tril(a), torch.tril(b)
+    if os.environ.get("PG_REC_MIN") == "0":
+        assert torch.equal(fa, fb)
+    else:
+        err = float((fa - fb).abs().max())
+        print("fused (recursive split) vs plain factor at n = 16384: max abs difference %.2e" % err)
+        assert err <= 5e-12
+    del b, fa, fb
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
     low = torch.tril(a)
