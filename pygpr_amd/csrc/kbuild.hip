@@ -734,10 +734,137 @@ __global__ __launch_bounds__(256) void pg_grad_kernel(pg_covspec spec, const dou
     }
 }
 
+// The contraction's fast body (round 4): fp64, ONE squared-exponential child (the common Compose([SE, WN])) and d <= 8 -- what round 3
+// did for the covariance build (kb_body<FAST>).  The general kernel above walks a thread's sixteen elements two at a time, each behind
+// its own degree-13 exponential chain: 0.82 ms at N = 16384, D = 8 for 1.07 GB of K^-1 (1.3 TB/s), a third of the fp64 issue rate.  Here
+//   * a thread owns a 4 x 4 micro-tile (rows ty*4 + r, columns v*32 + tx*2 + e: 16-byte loads of K^-1, 256-byte runs per row) whose
+//     sixteen elements are INDEPENDENT chains: distances, exponentials and weights interleave;
+//   * the inverse length scales are folded into the staged coordinates (one subtract + one FMA per coordinate; the partial sums of the
+//     length-scale entries then hold l_k^2 D_k^2 and the reduce divides by l_k: `presc`), differences stay DIRECT -- the per-coordinate
+//     squares are needed anyway, and they keep the weights of near-duplicate points exact;
+//   * the exponential is pg_exp_tab with sigma^2 folded into its table;
+//   * tiles strictly below the diagonal and inside the real points take a body without per-element tests (weight 2 everywhere).
+template <int DMAX>
+__global__ __launch_bounds__(256, 3) void pg_grad_fast_kernel(pg_covspec spec, const double* __restrict__ hp, const double* __restrict__ X,
+                                                           long ldx, int n, int d, const double* __restrict__ Kinv, long ldk,
+                                                           const double* __restrict__ alpha, double* __restrict__ part, int nhp) {
+    typedef double vec_t __attribute__((ext_vector_type(2)));
+    const int tr = blockIdx.y;
+    const int c0 = blockIdx.x * GCH, c1 = min(c0 + GCH, tr + 1);
+    const int blk = tr * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < nhp; idx += 256) part[(long)blk * nhp + idx] = 0.0;
+    if (c0 > tr) return;
+    __shared__ double red[4][DMAX + 2];
+    __shared__ double xr[DMAX * KT], xc[2][DMAX * KT], ar[KT], ac[2][KT], tab[32];
+    const int o = spec.off[0];
+    const double* scale = hp + o + 1;
+    auto stage = [&](double* dst, double* adst, int t0) {
+        for (int idx = tid; idx < KT * DMAX; idx += 256) {
+            const int p = idx / DMAX, k = idx % DMAX;
+            const int g = t0 * KT + p;
+            dst[k * KT + p] = (k < d && g < n) ? X[(long)g * ldx + k] * scale[k] : 0.0;
+        }
+        if (tid < KT) adst[tid] = (t0 * KT + tid < n) ? alpha[t0 * KT + tid] : 0.0;
+    };
+    stage(xr, ar, tr);
+    if (tid < 32) { const double sg = hp[o]; tab[tid] = sg * sg * pg_exp2_32[tid]; }
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[DMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= DMAX; ++k) acc[k] = 0.0;
+    double tr_w = 0.0;
+    for (int tc = c0, it = 0; tc < c1; ++tc, ++it) {
+        double* xb = xc[it & 1];
+        double* ab = ac[it & 1];
+        stage(xb, ab, tc);
+        const bool interior = tc < tr && (tr + 1) * KT <= n;
+        __syncthreads();   // publishes the staged tile; also orders this buffer's previous readers (two tiles ago) before the writes above
+        // The micro-tile in two halves of 4 rows x 2 columns (eight independent chains each).  All sixteen elements at once, or halves
+        // whose coordinates the compiler keeps in registers across both passes, need 170-270 VGPRs (one wave per SIMD): the column
+        // points of a half are held on purpose (2 DMAX doubles), the row points are re-read from LDS in the second pass.
+#pragma unroll 1
+        for (int v = 0; v < 2; ++v) {
+            const int cb = v * 32 + tx * 2;
+            const int gj0 = tc * KT + cb;
+            vec_t kin[4];     // this half's eight K^-1 values: in flight while the distances are summed (the row's stride ldk is even and covers the padding)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                kin[r] = *reinterpret_cast<const vec_t*>(Kinv + (long)min(tr * KT + ty * 4 + r, n - 1) * ldk + min(gj0, (int)ldk - 2));
+            vec_t b[DMAX];
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) b[k] = *reinterpret_cast<const vec_t*>(xb + k * KT + cb);
+            const vec_t aj = *reinterpret_cast<const vec_t*>(ab + cb);
+            double sq[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sq[r][0] = sq[r][1] = 0.0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const vec_t a01 = *reinterpret_cast<const vec_t*>(xr + k * KT + ty * 4), a23 = *reinterpret_cast<const vec_t*>(xr + k * KT + ty * 4 + 2);
+                const double a[4] = {a01[0], a01[1], a23[0], a23[1]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double df = a[r] - b[k][c];
+                        sq[r][c] = __builtin_fma(df, df, sq[r][c]);
+                    }
+            }
+            // W = weight * (K^-1 - a a^T), times the covariance value
+            double wb[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double ai = ar[ty * 4 + r];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double w = __builtin_fma(-ai, aj[c], kin[r][c]);
+                    if (interior) w *= 2.0;
+                    else {
+                        const int gi = tr * KT + ty * 4 + r, gj = gj0 + c;
+                        if (gi >= n || gj > gi) w = 0.0;
+                        else if (gj < gi) w *= 2.0;
+                        else tr_w += w;
+                    }
+                    wb[r][c] = w * pg_exp_tab(-sq[r][c], tab);
+                    acc[0] += wb[r][c];
+                }
+            }
+            asm volatile("" ::: "memory");    // second pass: re-read the row points instead of keeping 4 DMAX doubles alive
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const vec_t a01 = *reinterpret_cast<const vec_t*>(xr + k * KT + ty * 4), a23 = *reinterpret_cast<const vec_t*>(xr + k * KT + ty * 4 + 2);
+                const double a[4] = {a01[0], a01[1], a23[0], a23[1]};
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double df = a[r] - b[k][c];
+                        s = __builtin_fma(wb[r][c], df * df, s);
+                    }
+                acc[1 + k] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= DMAX; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    {
+        const double s = wave_sum(tr_w);
+        if (lane == 0) red[wave][DMAX + 1] = s;
+    }
+    __syncthreads();
+    if (tid <= d) part[(long)blk * nhp + o + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < spec.nnoise)
+        part[(long)blk * nhp + spec.noise_off[tid]] = red[0][DMAX + 1] + red[1][DMAX + 1] + red[2][DMAX + 1] + red[3][DMAX + 1];
+}
+
 // grad[p] = scale_p * sum_blocks part[b][p]
 __global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                              const double* __restrict__ part, int nblk, int nhp,
-                                                             int d, double* __restrict__ grad) {
+                                                             int d, double* __restrict__ grad, int presc) {
     __shared__ double red[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
@@ -755,6 +882,8 @@ __global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, co
             else if (p > o && p <= o + d) {
                 scale = (spec.kind[c] == PG_KIND_RBF) ? 0.5 * -2.0 * hp[p]   // -2 l_k D_k^2 K
                                                       : 0.5 * -(5.0 / 3.0) * hp[p];
+                // the fast contraction summed (l_k D_k)^2: -l_k S = -S' / l_k (l_k = 0: S' = 0 and the derivative is 0)
+                if (presc) scale = hp[p] != 0.0 ? -1.0 / hp[p] : 0.0;
                 mine = true;
             }
         }
@@ -787,7 +916,20 @@ int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, con
     const long need = (long)tiles * tiles * nhp;
     if (lwork < need) { pg_set_error("pg_nlml_grad: workspace %ld < %ld doubles", lwork, need); return -3; }
     int rc;
-    if (d <= 4) rc = launch_grad<T, 4>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    static const int fast_env = getenv("PG_GRAD_FAST") ? atoi(getenv("PG_GRAD_FAST")) : 1;
+    int presc = 0;
+    if constexpr (sizeof(T) == 8) {
+        // (d <= 8: with sixteen coordinates the held column points alone are 64 VGPRs and the kernel spills)
+        if (fast_env && spec.ncomp == 1 && spec.kind[0] == PG_KIND_RBF && d <= 8 && n >= 2 && ldk % 2 == 0) {
+            const dim3 grid((tiles + GCH - 1) / GCH, tiles);
+            if (d <= 4) hipLaunchKernelGGL(pg_grad_fast_kernel<4>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp);
+            else hipLaunchKernelGGL(pg_grad_fast_kernel<8>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp);
+            PG_CHECK(hipGetLastError());
+            presc = 1;
+        }
+    }
+    if (presc) rc = 0;
+    else if (d <= 4) rc = launch_grad<T, 4>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
     else if (d <= 8) rc = launch_grad<T, 8>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
     else if (d <= 16) rc = launch_grad<T, 16>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
     else if (d <= 32) rc = launch_grad<T, 32>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
@@ -795,7 +937,7 @@ int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, con
     else { pg_set_error("pg_nlml_grad: d=%d > %d", d, PG_MAX_DIM); return -2; }
     if (rc) return rc;
     hipLaunchKernelGGL(pg_grad_reduce_kernel, dim3(nhp), dim3(256), 0, st, spec, hp, work, tiles * ((tiles + GCH - 1) / GCH), nhp,
-                       d, grad);
+                       d, grad, presc);
     PG_CHECK(hipGetLastError());
     return 0;
 }

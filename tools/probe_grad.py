@@ -15,10 +15,12 @@ for d in (8, 16):
     x = torch.from_numpy(rng.random((n, d))).cuda()
     hp = torch.tensor([1.0] + [0.7] * d + [0.1], dtype=torch.float64).cuda()
     spec = make_spec([0], [0], [d + 1])
-    kinv = torch.randn(n, n, device="cuda", dtype=torch.float64)
-    alpha = torch.randn(n, device="cuda", dtype=torch.float64)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    kinv = torch.randn(n, n, device="cuda", dtype=torch.float64, generator=g)
+    alpha = torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
     grad = ops.zeros(d + 2); work = ops.empty(ops.nlml_grad_worksize(n, d + 2))
     t = ev(lambda: ops.nlml_grad(spec, hp, x, n, kinv, alpha, grad, work))
+    print("grad", grad.cpu().numpy())
     k = ops.empty(n, n)
     tb = ev(lambda: ops.kernel_build(spec, hp, x, None, k, lower_only=True, jitter=1e-7))
     tf = ev(lambda: ops.kernel_build(spec, hp, x, None, k, jitter=1e-7))
