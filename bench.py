@@ -353,7 +353,7 @@ def main():
     mine = {"rank": rank, "device_index": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
             "ms_per_step": 1e3 * elapsed_local / args.steps, "ms_per_eval_alone": ms_alone, "coupled_chain": ops.coupled_chain(),
             "coupled_panels_last_potrf": ops.last_coupled_panels(), "chain_timeouts": ops.chain_timeouts(),
-            "fallbacks": int(getattr(ops, "fallbacks", 0))}
+            "fallbacks": int(getattr(ops, "fallbacks", 0)), "chain_rearms": ops.chain_rearms()}
     out["dist"] = dist_report(1 + (d + 2) + world, mine)      # [NLML, gradient (nhp = d + 2), one status word per rank]
 
     local = exp = None

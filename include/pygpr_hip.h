@@ -259,11 +259,23 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches);
  * pg_set_coupled_chain(h, 1) re-creates the stream and probes again; pg_coupled_chain reads the state. */
 int pg_set_coupled_chain(pg_handle h, int on);
 int pg_coupled_chain(pg_handle h);
-/* Every wait of the coupled chain is bounded by wall time (default 2 s, PG_CS_SPIN_US in the environment at pg_create);
- * microseconds < 0 makes every wait expire at once -- the deterministic test hook of the fall-back path.  pg_chain_timeouts: how
- * many expiries this handle has seen (each one switched it to the classic chain; pg_set_coupled_chain(h, 1) probes and re-arms). */
+/* Every wait of the coupled chain is bounded by wall time.  microseconds = 0 (default; PG_CS_SPIN_US in the environment at
+ * pg_create overrides): the budget is scaled to the call -- 20x the factorisation's classic-chain estimate, at least 50 ms (n = 4096:
+ * 53 ms, 8192: 0.18 s, 16384: 1.0 s); > 0: that many microseconds per wait; < 0: every wait expires at once -- the deterministic test
+ * hook of the fall-back path.  pg_chain_timeouts: how many expiries this handle has seen.  Each one switches the handle to the classic
+ * chain, TEMPORARILY: after pg_set_rearm_after(h, calls) further factorisations (default 8; PG_CS_REARM; 0 = never) the handle probes
+ * its queues again and takes the coupled chain back by itself (pg_chain_rearms counts); pg_set_coupled_chain(h, 1) does so at once,
+ * pg_set_coupled_chain(h, -1) switches to the classic chain as a time-out would (stream kept, automatic re-arm applies),
+ * pg_set_coupled_chain(h, 0) for good (rows stream released). */
 int pg_set_spin_budget(pg_handle h, long microseconds);
 int pg_chain_timeouts(pg_handle h);
+int pg_set_rearm_after(pg_handle h, int calls);
+int pg_chain_rearms(pg_handle h);
+/* the budget of one wait for an n x n factorisation on this handle, microseconds (-1: forced expiry); and one bounded wait on a flag
+ * nobody sets with exactly that budget -- scratch: 32 bytes of device memory; afterwards ((long long*)scratch)[2] holds the 10 ns ticks
+ * waited and [3] whether the flag came (0: expired).  Diagnostics / tests; the handle's state is not changed. */
+long pg_wait_budget_us(pg_handle h, int n);
+int pg_spin_probe(pg_handle h, int n, void* scratch, void* stream);
 
 /* how many outer panels of the handle's LAST pg_potrf / pg_potrf_trtri ran on the flag-coupled chain (0: classic chain only;
  * the coupled chain needs the look-ahead schedule, i.e. at least three outer panels; any caller stream works, the legacy

@@ -77,6 +77,10 @@ _SIGS = {
     "pg_potrs": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp]),
     "pg_trsm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp]),
     "pg_set_spin_budget": (_i, [_vp, _l]),
+    "pg_set_rearm_after": (_i, [_vp, _i]),
+    "pg_chain_rearms": (_i, [_vp]),
+    "pg_wait_budget_us": (_l, [_vp, _i]),
+    "pg_spin_probe": (_i, [_vp, _i, _vp, _vp]),
     "pg_chain_timeouts": (_i, [_vp]),
     "pg_last_coupled_panels": (_i, [_vp]),
     "pg_set_coupled_chain": (_i, [_vp, _i]),

@@ -341,11 +341,31 @@ class HipOps:
         _lib.check(self.lib.pg_set_coupled_chain(self.h, int(on)), "pg_set_coupled_chain")
 
     def set_spin_budget(self, microseconds):
-        """Wall-time bound of one wait of the coupled chain; < 0: every wait expires at once (test hook of the fall-back)."""
+        """Wall-time bound of one wait of the coupled chain; 0: scaled to the call (default); < 0: every wait expires at once
+        (test hook of the fall-back)."""
         _lib.check(self.lib.pg_set_spin_budget(self.h, int(microseconds)), "pg_set_spin_budget")
 
     def chain_timeouts(self):
         return int(self.lib.pg_chain_timeouts(self.h))
+
+    def set_rearm_after(self, calls):
+        """After a time-out the handle takes the coupled chain back by itself once this many further factorisations have been
+        enqueued (default 8; 0: never)."""
+        _lib.check(self.lib.pg_set_rearm_after(self.h, int(calls)), "pg_set_rearm_after")
+
+    def chain_rearms(self):
+        return int(self.lib.pg_chain_rearms(self.h))
+
+    def wait_budget_us(self, n):
+        return int(self.lib.pg_wait_budget_us(self.h, int(n)))
+
+    def spin_probe(self, n):
+        """One bounded wait on a flag nobody sets, with the budget of an n x n factorisation: (milliseconds waited, flag came)."""
+        scratch = torch.zeros(4, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.pg_spin_probe(self.h, int(n), _p(scratch), self._st()), "pg_spin_probe")
+        torch.cuda.synchronize()
+        v = scratch.tolist()
+        return v[2] * 1e-5, bool(v[3])
 
     def recover_from_timeout(self):
         """A factorisation reported info = -1 (a wait of the coupled chain expired: include/pygpr_hip.h).  The library has
@@ -353,8 +373,8 @@ class HipOps:
         tell the caller to repeat its sequence from the covariance build."""
         torch.cuda.synchronize()
         self.chain_timeouts()                      # polls the pinned word
-        if self.coupled_chain():
-            _lib.check(self.lib.pg_set_coupled_chain(self.h, 0), "pg_set_coupled_chain")
+        if self.coupled_chain():                   # (-1: off as after a time-out -- the rows stream stays, the handle re-arms itself)
+            _lib.check(self.lib.pg_set_coupled_chain(self.h, -1), "pg_set_coupled_chain")
         self.fallbacks = getattr(self, "fallbacks", 0) + 1
 
     def build_factor_checked(self, spec, hp, x, a, invd, info, minv=None, jitter=JITTER):

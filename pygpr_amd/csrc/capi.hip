@@ -73,6 +73,7 @@ static void poll_timeout(pg_ctx* h) {
         const int v = *(volatile int*)h->tmo_host;     // epoch of the factorisation whose wait expired (chainstep.h)
         if (v) {
             *(volatile int*)h->tmo_host = 0;
+            if (h->coupled) { h->tmo_off = 1; h->calls_since_tmo = 0; }
             h->coupled = 0;
             if (v != h->counted_epoch) {               // one count per call, however many waits expired and whenever we looked
                 h->counted_epoch = v;
@@ -176,6 +177,20 @@ static int probe_concurrent_queues(pg_ctx* c) {
     (void)hipGetLastError();
     (void)hipHostFree(words);
     return ok;
+}
+
+// A handle whose chain was switched off by a time-out counts its factorisations; after rearm_after of them it probes the queues
+// again (2 ms at most, once) and takes the coupled chain back: the cause on record (profiles/r03_bench_n2_gloo_rehearsal.json: another
+// process's resident kernels on the same GPU) is transient, the downgrade should be too.
+static void maybe_rearm(pg_ctx* h) {
+    if (!h || !h->tmo_off || h->coupled || h->rearm_after <= 0) return;
+    if (++h->calls_since_tmo <= h->rearm_after) return;
+    h->calls_since_tmo = 0;
+    if (h->rows && h->spin_ticks >= 0 && probe_concurrent_queues(h)) {
+        h->coupled = 1;
+        h->tmo_off = 0;
+        h->rearms += 1;
+    }
 }
 
 template <typename T>
@@ -283,10 +298,15 @@ int pg_create(pg_handle* h) {
             if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->tmo_dev), c->tmo_host, 0) != hipSuccess) c->tmo_dev = nullptr;
         }
         (void)hipGetLastError();
+        // budget of one wait: by default scaled to the call (pg_potrf_t: 20x the classic-chain estimate of the coupled region, at least
+        // 50 ms -- round 3's flat 2 s was 70x a whole N = 16384 factorisation, and in a lock-step all-reduce one rank's stall is every
+        // rank's); PG_CS_SPIN_US / pg_set_spin_budget fix it
         const char* e = getenv("PG_CS_SPIN_US");
-        const long long us = e ? atoll(e) : 2000000LL;      // 2 s per wait: three orders of magnitude above any step of the chain
-        c->spin_ticks = us < 0 ? -1 : std::max<long long>(us, 1) * 100;
+        const long long us = e ? atoll(e) : 0;
+        c->spin_ticks = us < 0 ? -1 : us * 100;
         c->timeouts = 0;
+        const char* ra = getenv("PG_CS_REARM");
+        c->rearm_after = ra ? std::max(0, atoi(ra)) : 8;
     }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     {
@@ -357,6 +377,7 @@ int pg_build_potrf_trtri(pg_handle h, int dtype, const pg_covspec* spec, const d
                          double jitter, void* A, long lda, int n_pad, void* inv_diag, int* info, void* Minv, long ldm,
                          void* stream) {
     JOIN(h, stream);
+    maybe_rearm(h);
     NEED(h && hp && X && A && inv_diag && info, "null pointer");
     if (check_spec(spec, __func__, true)) return -1;
     NEED(n >= 0 && n_pad >= n && lda >= n_pad, "inconsistent sizes");
@@ -391,6 +412,7 @@ long pg_potrf_worksize(int dtype, int n) { (void)dtype; return pg_potrf_worksize
 
 int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* stream) {
     JOIN(h, stream);
+    maybe_rearm(h);
     NEED(h && A && inv_diag && info, "null pointer");
     AtomicGuard ag(h, A);
     NEED(lda >= n, "lda < n");
@@ -401,6 +423,7 @@ int pg_potrf(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, i
 int pg_potrf_trtri(pg_handle h, int dtype, int n, void* A, long lda, void* inv_diag, int* info, void* Minv, long ldm,
                    void* stream) {
     JOIN(h, stream);
+    maybe_rearm(h);
     NEED(h && A && inv_diag && info && Minv, "null pointer");
     NEED(lda >= n && ldm >= n && A != Minv, "bad leading dimension / aliasing");
     AtomicGuard ag(h, A);
@@ -679,6 +702,12 @@ int pg_profile(pg_handle h, int on) {
 }
 int pg_set_coupled_chain(pg_handle h, int on) {
     NEED(h, "null handle");
+    if (on < 0) {       // off for now, as after a time-out: the rows stream stays and the handle re-arms itself (pg_set_rearm_after)
+        if (h->coupled || h->tmo_off == 0) { h->tmo_off = h->rows ? 1 : 0; h->calls_since_tmo = 0; }
+        h->coupled = 0;
+        return 0;
+    }
+    h->tmo_off = 0;
     if (!on) {
         // off also RELEASES the rows stream (the handle then owns two streams)
         if (h->rows) {
@@ -715,8 +744,29 @@ int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
 
 int pg_set_spin_budget(pg_handle h, long microseconds) {
     NEED(h, "null handle");
-    h->spin_ticks = microseconds < 0 ? -1 : std::max<long long>(microseconds, 1) * 100;
+    h->spin_ticks = microseconds < 0 ? -1 : (long long)microseconds * 100;      // 0: scaled to the call
     return 0;
+}
+int pg_set_rearm_after(pg_handle h, int calls) {
+    NEED(h, "null handle");
+    NEED(calls >= 0, "calls must be >= 0 (0: never re-arm automatically)");
+    h->rearm_after = calls;
+    return 0;
+}
+int pg_chain_rearms(pg_handle h) { return h ? h->rearms : -1; }
+long pg_wait_budget_us(pg_handle h, int n) {
+    if (!h) return 0;
+    const long long t = pg_wait_ticks(h, n);
+    return t < 0 ? -1 : (long)(t / 100);
+}
+// scratch: 4 ints + 2 long longs of device memory (32 bytes, 8-byte aligned).  The handle's state is not touched (no pinned word, no
+// switch to the classic chain): the probe only measures the wait.
+int pg_spin_probe(pg_handle h, int n, void* scratch, void* stream) {
+    NEED(h && scratch, "null pointer");
+    PG_CHECK(hipMemsetAsync(scratch, 0, 32, ST(stream)));
+    int* w = reinterpret_cast<int*>(scratch);
+    const CsWait cw = {w + 1, nullptr, pg_wait_ticks(h, n), 1};
+    return pg_spin_probe_launch(ST(stream), w, cw, reinterpret_cast<long long*>(w + 4));
 }
 int pg_chain_timeouts(pg_handle h) {
     if (!h) return -1;
@@ -737,6 +787,7 @@ int pg_build_potrf_trtri_checked(pg_handle h, int dtype, const pg_covspec* spec,
         PG_CHECK(hipStreamSynchronize(ST(stream)));
         if (*info_host >= 0) return 0;
         poll_timeout(h);
+        if (h->coupled) { h->tmo_off = 1; h->calls_since_tmo = 0; }
         h->coupled = 0;        // whatever the pinned word said: the repeat must not take the coupled chain
     }
     return 0;

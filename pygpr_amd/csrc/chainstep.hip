@@ -420,3 +420,17 @@ int pg_flagset(hipStream_t st, int* flag, int value) {
     PG_CHECK(hipGetLastError());
     return 0;
 }
+
+// One lane waiting for a flag nobody sets, with the budget the factorisation of an n x n matrix would use: what a wait of the coupled
+// chain costs when its partner never comes (tests).  out[0] = 10 ns ticks waited, out[1] = 1 if the flag came, 0 on expiry.
+__global__ void pg_spin_probe_kernel(int* flag, CsWait w, long long* out) {
+    const long long t0 = (long long)wall_clock64();
+    const bool ok = cs_spin_ge(flag, 1, w);
+    out[0] = (long long)wall_clock64() - t0;
+    out[1] = ok ? 1 : 0;
+}
+int pg_spin_probe_launch(hipStream_t st, int* flag, const CsWait& w, long long* out) {
+    hipLaunchKernelGGL(pg_spin_probe_kernel, dim3(1), dim3(1), 0, st, flag, w, out);
+    PG_CHECK(hipGetLastError());
+    return 0;
+}

@@ -34,8 +34,12 @@ struct pg_ctx {
     hipStream_t side_owner;   // the caller stream that work was forked from: only a join on THAT stream clears side_pending
     int* tmo_host;            // pinned host word a timed-out wait of the coupled chain sets (chainstep.h); polled at every entry point
     int* tmo_dev;             // its device address
-    long long spin_ticks;     // budget of one wait of the coupled chain in 10 ns ticks (< 0: forced expiry, test hook)
+    long long spin_ticks;     // budget of one wait of the coupled chain in 10 ns ticks (< 0: forced expiry, test hook; 0: scaled to the call, pg_potrf_t)
     int timeouts;             // coupled-chain time-outs seen on this handle (each switched the handle to the classic chain)
+    int tmo_off;              // the chain is off BECAUSE of a time-out (not by the caller's choice or a failed probe): re-armed automatically
+    int calls_since_tmo;      // factorisations enqueued on the classic chain since then
+    int rearm_after;          // ... after this many of them the handle probes again and re-arms (pg_set_rearm_after / PG_CS_REARM; 0: never)
+    int rearms;               // automatic re-arms so far
     int chain_epoch;          // counts the factorisations that took the coupled chain; an expiry reports its call's number
     int counted_epoch;        // the last epoch whose time-out was counted
     int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory

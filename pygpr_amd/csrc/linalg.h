@@ -2,6 +2,7 @@
 #include "common.h"
 #include "pygpr_hip.h"
 long pg_potrf_worksize_impl(int n);
+long long pg_wait_ticks(const pg_ctx* ctx, int n);   // budget of one wait of the coupled chain for an n x n factorisation, 10 ns ticks
 // A covariance build folded into the factorisation (pg_build_potrf_trtri): A is written by pg_potrf_t itself, the first outer
 // panel's columns before the look-ahead starts and the rest on the update stream while the first panel's chain runs.
 template <typename T> struct BuildReq {

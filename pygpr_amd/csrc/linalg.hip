@@ -469,6 +469,12 @@ static int trtri_top(pg_ctx* ctx, hipStream_t st, int h1, int h2, const T* L, lo
     return 0;
 }
 
+long long pg_wait_ticks(const pg_ctx* ctx, int n) {
+    if (ctx->spin_ticks != 0) return ctx->spin_ticks;
+    const double est_us = 62.0 * (n / NB) + (double)n * n * n / 3.0 / 35.0e6;
+    return (long long)(std::max(50000.0, 20.0 * est_us) * 100.0);
+}
+
 static int pool_event(pg_ctx* ctx, int idx, hipEvent_t* ev) {
     if (idx >= ctx->npool) {
         const int want = idx + 16;
@@ -658,7 +664,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     int* f_browe = f_early + nblk;              // [nblk] workgroups that have published the first 64 columns of X[block row b+1, block column b]
     int* f_tmo = f_browe + nblk;                // sticky time-out word
     if (o_s < npan) ctx->chain_epoch = ctx->chain_epoch % 1000000 + 1;
-    const CsWait cw = {f_tmo, ctx->tmo_dev, ctx->spin_ticks, ctx->chain_epoch};
+    // budget of one wait (10 ns ticks): the caller's (pg_set_spin_budget / PG_CS_SPIN_US), or 20x what this factorisation takes on the
+    // classic chain by a crude model (62 us per 128 columns + n^3 / 3 flop at 35 TFLOP/s), at least 50 ms -- a leaf's wait may cover a
+    // whole trailing update of the part before the coupled region (3 ms at n = 16384), never a multiple of the call
+    const CsWait cw = {f_tmo, ctx->tmo_dev, pg_wait_ticks(ctx, n), ctx->chain_epoch};
     // two-phase hand-over (chainstep.hip): only the third leaf form raises the early flag
     static const bool two_phase_env = !(getenv("PG_CS_TWO_PHASE") && atoi(getenv("PG_CS_TWO_PHASE")) == 0);
     const bool two_phase = two_phase_env && pg_leaf_has_early();

@@ -958,7 +958,7 @@ def forced_timeout(ops):
     assert ops.coupled_chain() == 1
     ops.set_spin_budget(-1)
     yield
-    ops.set_spin_budget(2_000_000)
+    ops.set_spin_budget(0)
     ops.set_coupled_chain(1)
     assert ops.coupled_chain() == 1
 
@@ -1010,6 +1010,67 @@ def test_build_potrf_trtri_checked_falls_back_inside_the_call(ops, forced_timeou
     t0 = time.perf_counter()
     assert ops.build_factor_checked(spec, hpd, xd, a, invd, info, minv, jitter=1e-7) == 0
     assert time.perf_counter() - t0 < 0.25 and ops.last_coupled_panels() == 0
+
+
+@pytest.mark.gpu
+def test_a_timeout_is_temporary_the_handle_rearms_itself(ops):
+    """Round 4: a time-out switches the handle to the classic chain only for pg_set_rearm_after(h, K) further factorisations; the next
+    one probes the queues again and takes the coupled chain back by itself (round 3: the downgrade lasted for the life of the handle,
+    profiles/r03_bench_n2_gloo_rehearsal.json).  Forced expiry -> fall-back, K = 3 clean calls on the classic chain, automatic
+    re-arm, pg_last_coupled_panels() > 0 again, LAPACK's factor throughout.  The wait budget is back on its default (scaled to the
+    call) while the classic calls run."""
+    n = 3072
+    a = spd(n, np.random.default_rng(29))
+    chol = np.linalg.cholesky(a)
+    assert ops.coupled_chain() == 1
+    rearms, tmos = ops.chain_rearms(), ops.chain_timeouts()
+    ops.set_rearm_after(3)
+    try:
+        ops.set_spin_budget(-1)
+        _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+        assert info == -1 and coupled == coupled_count(n)
+        ops.set_spin_budget(0)
+        assert ops.chain_timeouts() == tmos + 1 and ops.coupled_chain() == 0
+        for _ in range(3):
+            ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
+            assert info == 0 and coupled == 0 and ops.coupled_chain() == 0 and ops.chain_rearms() == rearms
+            np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
+        ad, _, info, coupled = _potrf_on_compute_stream(ops, a)      # the K+1-th call re-arms before it factorises
+        assert info == 0 and coupled == coupled_count(n) and ops.coupled_chain() == 1 and ops.chain_rearms() == rearms + 1
+        np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
+        # a caller's explicit "off" is not a time-out: no automatic re-arm
+        ops.set_coupled_chain(0)
+        for _ in range(5):
+            _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+            assert info == 0 and coupled == 0
+        assert ops.coupled_chain() == 0 and ops.chain_rearms() == rearms + 1
+    finally:
+        ops.set_rearm_after(8)
+        ops.set_spin_budget(0)
+        ops.set_coupled_chain(1)
+    assert ops.coupled_chain() == 1
+
+
+@pytest.mark.gpu
+def test_wait_budget_is_scaled_to_the_call(ops):
+    """The default budget of one wait is 20x the call's classic-chain estimate, at least 50 ms -- not round 3's flat 2 s (70x a whole
+    N = 16384 factorisation; in a lock-step all-reduce one rank's stall is every rank's).  The figures, and a REAL wait on a flag nobody
+    sets with the budget of n = 3072: it gives up after about 50 ms."""
+    assert ops.wait_budget_us(2048) == 50_000 and 50_000 <= ops.wait_budget_us(4096) < 60_000
+    assert 150_000 < ops.wait_budget_us(8192) < 250_000 and 800_000 < ops.wait_budget_us(16384) < 1_300_000
+    try:
+        ops.set_spin_budget(1234)
+        assert ops.wait_budget_us(16384) == 1234
+        ops.set_spin_budget(-1)
+        assert ops.wait_budget_us(16384) == -1
+        ms, came = ops.spin_probe(3072)
+        assert not came and ms < 1.0
+    finally:
+        ops.set_spin_budget(0)
+    before = ops.chain_timeouts()
+    ms, came = ops.spin_probe(3072)
+    assert not came and 45.0 <= ms <= 80.0
+    assert ops.chain_timeouts() == before and ops.coupled_chain() == 1      # the probe does not touch the handle
 
 
 # ---- batched experts: one call, every launch covers all of them (PyGPR/gpr.py:65-74 factorises a batch in one tc.cholesky) ------

@@ -657,7 +657,7 @@ def test_class_surface_survives_a_coupled_chain_timeout():
         np.testing.assert_allclose(val, l_ref, rtol=1e-10)
         np.testing.assert_allclose(grad, g_ref, rtol=1e-8, atol=1e-8 * np.abs(g_ref).max())
     finally:
-        ops.set_spin_budget(2_000_000)
+        ops.set_spin_budget(0)
         ops.set_coupled_chain(1)
     assert ops.coupled_chain() == 1
     val2, _ = pg.MLE(gp).loss_and_grad(hp.copy())          # re-armed: the coupled chain runs again and agrees
