@@ -181,6 +181,23 @@ int pg_nlml_grad(pg_handle h, int dtype, const pg_covspec* spec, const double* h
                  int d, const void* Kinv, long ldk, const void* alpha, double* grad, int nhp, double* work,
                  long lwork, void* stream);
 
+/* The gradient path for nexp batched experts of one size (round 4): what loss.py:92-128 does in ONE batched factor / solve when the
+ * model carries a leading expert dimension (x [nc, n, d] built at gr_bcm.py:19-29, params [nc, nhp]).  After
+ * pg_build_potrf_trtri_batched:
+ *   pg_alpha_nlml_batched : alpha_e = Minv_e^T (Minv_e y_e) and out[e * out_stride] = NLML_e (log det from the diagonal of Minv_e),
+ *                           four launches for the whole batch (u: n, work: (n/256) n scratch elements per expert)
+ *   pg_lauum_batched      : Kinv_e = Minv_e^T Minv_e (lower tiles), one launch
+ *   pg_nlml_grad_batched  : grad[e * grad_stride + k] as pg_nlml_grad, two launches; work: nexp * pg_nlml_grad_worksize(n, nhp) doubles
+ * Strides are in elements; x_stride / hp_stride / y_stride = 0 shares points / hyper-parameters / targets between the experts. */
+int pg_alpha_nlml_batched(pg_handle h, int dtype, int n_real, int n, const void* Minv, long ldm, long m_stride, const void* y, long y_stride,
+                          void* u, long u_stride, void* alpha, long alpha_stride, void* work, long work_stride, double* out, long out_stride,
+                          int nexp, void* stream);
+int pg_lauum_batched(pg_handle h, int dtype, int n, const void* Minv, long ldm, long m_stride, void* Kinv, long ldk, long k_stride, int nexp,
+                     void* stream);
+int pg_nlml_grad_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* X, long ldx, long x_stride,
+                         int n, int d, const void* Kinv, long ldk, long k_stride, const void* alpha, long alpha_stride, double* grad,
+                         long grad_stride, int nhp, double* work, long lwork, int nexp, void* stream);
+
 /* Predictive mean and variance from Ks[n_pad x m_pad] = k(X, Xp) (train rows, test columns):
  *   mean[j] = sum_i Ks[i][j] alpha[i]                 (gpr.py:80-85)
  *   var[j]  = kss - sum_i (Minv Ks)[i][j]^2           (gpr.py:98-104: diag(K**) - rowsum(K* o (K^-1 K*^T)^T))

@@ -47,6 +47,9 @@ _SIGS = {
     "pg_potri": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
     "pg_logdet": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp]),
     "pg_trmv": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp]),
+    "pg_alpha_nlml_batched": (_i, [_vp, _i, _i, _i, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _vp]),
+    "pg_lauum_batched": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp]),
+    "pg_nlml_grad_batched": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _l, _vp, _l, _l, _i, _i, _vp, _l, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp]),
     "pg_alpha_nlml_async": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_nlml_value": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp]),
     "pg_nlml_grad_worksize": (_l, [_i, _i]),

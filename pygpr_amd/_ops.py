@@ -163,6 +163,33 @@ class HipOps:
                                              alpha_all.stride(0), _p(work_all), work_all.stride(0), minv_all.shape[0], self._st()),
                    "pg_alpha_batched")
 
+    def alpha_nlml_batched(self, minv_all, y_all, u_all, alpha_all, work_all, n, out_all):
+        """alpha_e and NLML_e for all experts (pg_alpha_nlml_batched): out_all [nexp, >= 1] float64 receives NLML_e in column 0."""
+        self._chk(minv_all, y_all, u_all, alpha_all, work_all, None)
+        assert out_all.dtype == torch.float64 and out_all.is_cuda
+        _lib.check(self.lib.pg_alpha_nlml_batched(
+            self.h, _code(minv_all.dtype), int(n), minv_all.shape[1], _p(minv_all), minv_all.stride(1), minv_all.stride(0), _p(y_all),
+            y_all.stride(0) if y_all.shape[0] > 1 else 0, _p(u_all), u_all.stride(0), _p(alpha_all), alpha_all.stride(0), _p(work_all),
+            work_all.stride(0), _p(out_all), out_all.stride(0), minv_all.shape[0], self._st()), "pg_alpha_nlml_batched")
+
+    def lauum_batched(self, minv_all, kinv_all):
+        self._chk(minv_all, kinv_all)
+        _lib.check(self.lib.pg_lauum_batched(self.h, _code(minv_all.dtype), minv_all.shape[1], _p(minv_all), minv_all.stride(1),
+                                             minv_all.stride(0), _p(kinv_all), kinv_all.stride(1), kinv_all.stride(0), minv_all.shape[0],
+                                             self._st()), "pg_lauum_batched")
+
+    def nlml_grad_batched(self, spec, hp_all, x_all, x_stride, n, kinv_all, alpha_all, grad_all, work):
+        """grad_all [nexp, >= nhp] (a view with row stride: e.g. outs[:, 1:]) <- every expert's gradient in two launches."""
+        passes = _passes(spec)
+        self._chk(hp_all, x_all, kinv_all, alpha_all, work)
+        assert grad_all.dtype == torch.float64 and grad_all.is_cuda and grad_all.stride(-1) == 1
+        nexp, nhp = kinv_all.shape[0], hp_all.shape[-1]
+        for sp in passes:
+            _lib.check(self.lib.pg_nlml_grad_batched(
+                self.h, _code(kinv_all.dtype), C.byref(sp), _p(hp_all), hp_all.stride(0), _p(x_all), x_all.stride(-2), int(x_stride), int(n),
+                x_all.shape[-1], _p(kinv_all), kinv_all.stride(1), kinv_all.stride(0), _p(alpha_all), alpha_all.stride(0), _p(grad_all),
+                grad_all.stride(0), nhp, _p(work), work.numel(), nexp, self._st()), "pg_nlml_grad_batched")
+
     def potrf_trtri(self, a, invd, info, minv):
         """Cholesky in place + minv = L^-1, fused so that part of the inverse overlaps the factorisation's tail."""
         self._chk(a, invd, info, minv)

@@ -529,6 +529,45 @@ int pg_alpha_batched(pg_handle h, int dtype, int n, const void* Minv, long ldm, 
                                        (float*)alpha, alpha_stride, (float*)work, work_stride, nexp));
 }
 
+int pg_alpha_nlml_batched(pg_handle h, int dtype, int n_real, int n, const void* Minv, long ldm, long m_stride, const void* y, long y_stride,
+                          void* u, long u_stride, void* alpha, long alpha_stride, void* work, long work_stride, double* out, long out_stride,
+                          int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Minv && y && u && alpha && work && out, "null pointer");
+    NEED(n_real > 0 && n_real <= n && ldm >= n && nexp >= 1 && nexp <= 65535, "bad size");
+    DISPATCH(dtype,
+             pg_alpha_batched_t<double>(ST(stream), n, (const double*)Minv, ldm, m_stride, (const double*)y, y_stride, (double*)u, u_stride,
+                                        (double*)alpha, alpha_stride, (double*)work, work_stride, nexp, n_real, out, out_stride),
+             pg_alpha_batched_t<float>(ST(stream), n, (const float*)Minv, ldm, m_stride, (const float*)y, y_stride, (float*)u, u_stride,
+                                       (float*)alpha, alpha_stride, (float*)work, work_stride, nexp, n_real, out, out_stride));
+}
+
+int pg_lauum_batched(pg_handle h, int dtype, int n, const void* Minv, long ldm, long m_stride, void* Kinv, long ldk, long k_stride, int nexp,
+                     void* stream) {
+    JOIN(h, stream);
+    NEED(h && Minv && Kinv, "null pointer");
+    NEED(Minv != Kinv, "pg_lauum_batched is out of place");
+    NEED(nexp >= 1 && nexp <= 65535 && ldm >= n && ldk >= n, "bad size");
+    NEED(nexp == 1 || (m_stride >= (long)n * ldm && k_stride >= (long)n * ldk), "experts' matrices overlap");
+    ExpBatch eb;
+    eb.nexp = nexp; eb.eA = k_stride; eb.eInv = 0; eb.eM = m_stride; eb.eX = 0; eb.ehp = 0;
+    DISPATCH(dtype, pg_lauum_t<double>(h, ST(stream), n, (const double*)Minv, ldm, (double*)Kinv, ldk, &eb),
+             pg_lauum_t<float>(h, ST(stream), n, (const float*)Minv, ldm, (float*)Kinv, ldk, &eb));
+}
+
+int pg_nlml_grad_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* X, long ldx, long x_stride,
+                         int n, int d, const void* Kinv, long ldk, long k_stride, const void* alpha, long alpha_stride, double* grad,
+                         long grad_stride, int nhp, double* work, long lwork, int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && hp && X && Kinv && alpha && grad && work, "null pointer");
+    if (check_spec(spec, __func__)) return -1;
+    DISPATCH(dtype,
+             pg_nlml_grad_t<double>(ST(stream), *spec, hp, (const double*)X, ldx, n, d, (const double*)Kinv, ldk, (const double*)alpha, grad,
+                                    nhp, work, lwork, nexp, hp_stride, x_stride, k_stride, alpha_stride, grad_stride),
+             pg_nlml_grad_t<float>(ST(stream), *spec, hp, (const float*)X, ldx, n, d, (const float*)Kinv, ldk, (const float*)alpha, grad, nhp,
+                                   work, lwork, nexp, hp_stride, x_stride, k_stride, alpha_stride, grad_stride));
+}
+
 int pg_alpha_nlml_async(pg_handle h, int dtype, int n_real, int n, const void* L, long ldl, const void* Minv, long ldm, const void* y,
                         void* u, void* alpha, void* work, double* out, void* stream) {
     JOIN(h, stream);

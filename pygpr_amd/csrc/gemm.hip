@@ -313,9 +313,20 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
     const int tm = p.M / BM, tn = p.N / BN;
     const long tiles = p.tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
     if (tiles == 0 || p.batch == 0 || p.nexp == 0) return 0;
-    dim3 grid((unsigned)tiles, (unsigned)(p.batch * p.nexp), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
-    PG_CHECK(hipGetLastError());
+    if (p.batch > 65535) { pg_set_error("pg_gemm: batch=%d exceeds the grid's y limit", p.batch); return -2; }
+    // grid.y = batch * nexp is limited to 65535: many small experts go in chunks of whole experts (each launch addresses its experts
+    // from 0, so the operand and status pointers move with the chunk)
+    const int per = std::max(1, 65535 / p.batch);
+    for (int e0 = 0; e0 < p.nexp; e0 += per) {
+        GemmP<T> q = p;
+        q.nexp = std::min(per, p.nexp - e0);
+        q.A = p.A + (long)e0 * p.eA; q.B = p.B + (long)e0 * p.eB;
+        if (p.C) q.C = p.C + (long)e0 * p.eC;
+        if (p.info) q.info = p.info + (long)e0 * p.einfo;
+        dim3 grid((unsigned)tiles, (unsigned)(q.batch * q.nexp), 1);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, q);
+        PG_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

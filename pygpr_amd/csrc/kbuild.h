@@ -9,7 +9,8 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
               int nexp = 1, long eX = 0, long ehp = 0, long eK = 0);               // batched experts: strides of X, hp and K
 template <typename T>
 int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,
-                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork);
+                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork,
+                   int nexp = 1, long ehp = 0, long eX = 0, long eK = 0, long ea = 0, long egrad = 0);   // batched experts: strides
 long pg_nlml_grad_worksize_impl(int n, int nhp);
 template <typename T>
 int pg_centres(hipStream_t st, const T* X, long ldx, int n, const T* Cn, long ldc, int m, int d, T* D, long ldd, int* idx);

@@ -621,12 +621,17 @@ template int pg_centres<float>(hipStream_t, const float*, long, int, const float
 // N = 16384, D = 8 (contraction + reduce): one tile per workgroup 873 + 120 us, strips of 4 826 + 33 us, strips of 16
 // 1061 + 11 us (imbalance); keeping the column point and squared differences in registers (138 VGPRs) 1179 us.
 #define GCH 4
+struct GradBatch {          // strides between batched experts (elements); all zero for one expert
+    long eX, ehp, eK, ea, epart, egrad;
+};
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void pg_grad_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                       const T* __restrict__ X, long ldx, int n, int d,
                                                       const T* __restrict__ Kinv, long ldk,
                                                       const T* __restrict__ alpha, double* __restrict__ part,
-                                                      int nhp) {
+                                                      int nhp, GradBatch gb) {
+    // batched experts: blockIdx.z = expert, each with its own points, hyper-parameters, K^-1, weights and partial sums
+    X += blockIdx.z * gb.eX; hp += blockIdx.z * gb.ehp; Kinv += blockIdx.z * gb.eK; alpha += blockIdx.z * gb.ea; part += blockIdx.z * gb.epart;
     const int tr = blockIdx.y;
     const int c0 = blockIdx.x * GCH, c1 = min(c0 + GCH, tr + 1);   // column tiles [c0, c1), none above the diagonal
     const int blk = tr * gridDim.x + blockIdx.x;
@@ -747,8 +752,9 @@ __global__ __launch_bounds__(256) void pg_grad_kernel(pg_covspec spec, const dou
 template <int DMAX>
 __global__ __launch_bounds__(256, 3) void pg_grad_fast_kernel(pg_covspec spec, const double* __restrict__ hp, const double* __restrict__ X,
                                                            long ldx, int n, int d, const double* __restrict__ Kinv, long ldk,
-                                                           const double* __restrict__ alpha, double* __restrict__ part, int nhp) {
+                                                           const double* __restrict__ alpha, double* __restrict__ part, int nhp, GradBatch gb) {
     typedef double vec_t __attribute__((ext_vector_type(2)));
+    X += blockIdx.z * gb.eX; hp += blockIdx.z * gb.ehp; Kinv += blockIdx.z * gb.eK; alpha += blockIdx.z * gb.ea; part += blockIdx.z * gb.epart;
     const int tr = blockIdx.y;
     const int c0 = blockIdx.x * GCH, c1 = min(c0 + GCH, tr + 1);
     const int blk = tr * gridDim.x + blockIdx.x;
@@ -864,8 +870,9 @@ __global__ __launch_bounds__(256, 3) void pg_grad_fast_kernel(pg_covspec spec, c
 // grad[p] = scale_p * sum_blocks part[b][p]
 __global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, const double* __restrict__ hp,
                                                              const double* __restrict__ part, int nblk, int nhp,
-                                                             int d, double* __restrict__ grad, int presc) {
+                                                             int d, double* __restrict__ grad, int presc, GradBatch gb) {
     __shared__ double red[4];
+    hp += blockIdx.z * gb.ehp; part += blockIdx.z * gb.epart; grad += blockIdx.z * gb.egrad;
     const int p = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
     for (int b = tid; b < nblk; b += 256) s += part[(long)b * nhp + p];
@@ -895,7 +902,7 @@ __global__ __launch_bounds__(256) void pg_grad_reduce_kernel(pg_covspec spec, co
 
 template <typename T, int DMAX>
 static int launch_grad(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n,
-                       int d, const T* Kinv, long ldk, const T* alpha, double* part, int nhp, int tiles) {
+                       int d, const T* Kinv, long ldk, const T* alpha, double* part, int nhp, int tiles, const GradBatch& gb, int nexp) {
     const size_t lds = (size_t)(3 * KT * DMAX + PG_MAX_COMP * DMAX) * sizeof(T) + 4 * (DMAX + 2) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {   // d > 32 needs more than the 64 KB a kernel gets without opting in
@@ -903,41 +910,44 @@ static int launch_grad(hipStream_t st, const pg_covspec& spec, const double* hp,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((pg_grad_kernel<T, DMAX>), dim3((tiles + GCH - 1) / GCH, tiles), dim3(256), lds, st, spec, hp, X, ldx,
-                       n, d, Kinv, ldk, alpha, part, nhp);
+    hipLaunchKernelGGL((pg_grad_kernel<T, DMAX>), dim3((tiles + GCH - 1) / GCH, tiles, nexp), dim3(256), lds, st, spec, hp, X, ldx,
+                       n, d, Kinv, ldk, alpha, part, nhp, gb);
     PG_CHECK(hipGetLastError());
     return 0;
 }
 
 template <typename T>
 int pg_nlml_grad_t(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d,
-                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork) {
+                   const T* Kinv, long ldk, const T* alpha, double* grad, int nhp, double* work, long lwork,
+                   int nexp, long ehp, long eX, long eK, long ea, long egrad) {
     const int tiles = (n + KT - 1) / KT;
     const long need = (long)tiles * tiles * nhp;
-    if (lwork < need) { pg_set_error("pg_nlml_grad: workspace %ld < %ld doubles", lwork, need); return -3; }
+    if (nexp < 1 || nexp > 65535) { pg_set_error("pg_nlml_grad: 1 <= nexp <= 65535"); return -2; }
+    if (lwork < need * nexp) { pg_set_error("pg_nlml_grad: workspace %ld < %ld doubles", lwork, need * nexp); return -3; }
+    const GradBatch gb = {eX, ehp, eK, ea, need, egrad};
     int rc;
     static const int fast_env = getenv("PG_GRAD_FAST") ? atoi(getenv("PG_GRAD_FAST")) : 1;
     int presc = 0;
     if constexpr (sizeof(T) == 8) {
         // (d <= 8: with sixteen coordinates the held column points alone are 64 VGPRs and the kernel spills)
         if (fast_env && spec.ncomp == 1 && spec.kind[0] == PG_KIND_RBF && d <= 8 && n >= 2 && ldk % 2 == 0) {
-            const dim3 grid((tiles + GCH - 1) / GCH, tiles);
-            if (d <= 4) hipLaunchKernelGGL(pg_grad_fast_kernel<4>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp);
-            else hipLaunchKernelGGL(pg_grad_fast_kernel<8>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp);
+            const dim3 grid((tiles + GCH - 1) / GCH, tiles, nexp);
+            if (d <= 4) hipLaunchKernelGGL(pg_grad_fast_kernel<4>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, gb);
+            else hipLaunchKernelGGL(pg_grad_fast_kernel<8>, grid, dim3(256), 0, st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, gb);
             PG_CHECK(hipGetLastError());
             presc = 1;
         }
     }
     if (presc) rc = 0;
-    else if (d <= 4) rc = launch_grad<T, 4>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
-    else if (d <= 8) rc = launch_grad<T, 8>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
-    else if (d <= 16) rc = launch_grad<T, 16>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
-    else if (d <= 32) rc = launch_grad<T, 32>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
-    else if (d <= 64) rc = launch_grad<T, 64>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles);
+    else if (d <= 4) rc = launch_grad<T, 4>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles, gb, nexp);
+    else if (d <= 8) rc = launch_grad<T, 8>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles, gb, nexp);
+    else if (d <= 16) rc = launch_grad<T, 16>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles, gb, nexp);
+    else if (d <= 32) rc = launch_grad<T, 32>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles, gb, nexp);
+    else if (d <= 64) rc = launch_grad<T, 64>(st, spec, hp, X, ldx, n, d, Kinv, ldk, alpha, work, nhp, tiles, gb, nexp);
     else { pg_set_error("pg_nlml_grad: d=%d > %d", d, PG_MAX_DIM); return -2; }
     if (rc) return rc;
-    hipLaunchKernelGGL(pg_grad_reduce_kernel, dim3(nhp), dim3(256), 0, st, spec, hp, work, tiles * ((tiles + GCH - 1) / GCH), nhp,
-                       d, grad, presc);
+    hipLaunchKernelGGL(pg_grad_reduce_kernel, dim3(nhp, 1, nexp), dim3(256), 0, st, spec, hp, work, tiles * ((tiles + GCH - 1) / GCH), nhp,
+                       d, grad, presc, gb);
     PG_CHECK(hipGetLastError());
     return 0;
 }
@@ -946,6 +956,6 @@ long pg_nlml_grad_worksize_impl(int n, int nhp) {
     return tiles * tiles * nhp;
 }
 template int pg_nlml_grad_t<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int, int,
-                                    const double*, long, const double*, double*, int, double*, long);
+                                    const double*, long, const double*, double*, int, double*, long, int, long, long, long, long, long);
 template int pg_nlml_grad_t<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int, int,
-                                   const float*, long, const float*, double*, int, double*, long);
+                                   const float*, long, const float*, double*, int, double*, long, int, long, long, long, long, long);

@@ -32,11 +32,11 @@ template <typename T> int pg_logdet_t(hipStream_t, int n, const T* L, long ldl, 
 template <typename T>
 int pg_potrs_t(pg_ctx*, hipStream_t, int n, int nrhs, const T* L, long ldl, const T* invD, const T* Minv, long ldm, const T* B, long ldb,
                T* X, long ldx, T* work, int both);
-template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk);
+template <typename T> int pg_lauum_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, T* Kinv, long ldk, const ExpBatch* eb = nullptr);
 template <typename T> int pg_trmv_t(pg_ctx*, hipStream_t, int n, const T* M, long ldm, int trans, const T* x, T* y, T* work);
 template <typename T>
 int pg_alpha_batched_t(hipStream_t, int n, const T* M, long ldm, long eM, const T* y, long ey, T* u, long eu, T* alpha, long ea, T* work, long ew,
-                       int nexp);
+                       int nexp, int n_real = 0, double* out = nullptr, long eo = 0);
 template <typename T>
 int pg_alpha_nlml_async_t(pg_ctx*, hipStream_t, int n_real, int n, const T* L, long ldl, const T* Minv, long ldm, const T* y, T* u,
                           T* alpha, T* work, double* out);

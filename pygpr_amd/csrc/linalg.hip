@@ -981,11 +981,12 @@ int pg_potrs_t(pg_ctx* ctx, hipStream_t st, int n, int nrhs, const T* L, long ld
 }
 
 template <typename T>
-int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv, long ldk) {
+int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv, long ldk, const ExpBatch* eb) {
     if (n <= 0 || n % PG_PAD) { pg_set_error("pg_lauum: n=%d is not a positive multiple of %d", n, PG_PAD); return -2; }
     GemmP<T> p = gp0<T>();
     p.M = p.N = p.K = n; p.A = M; p.lda = ldm; p.B = M; p.ldb = ldm; p.C = Kinv; p.ldc = ldk;
     p.tri = 1; p.klo = 1;
+    if (eb) { p.nexp = eb->nexp; p.eA = p.eB = eb->eM; p.eC = eb->eA; }      // experts together: Minv + e eM -> Kinv + e eA
     return pg_gemm<T>(ctx, st, GEMM_TN_128, p);
 }
 
@@ -1002,14 +1003,32 @@ int pg_trmv_t(pg_ctx*, hipStream_t st, int n, const T* M, long ldm, int trans, c
     return 0;
 }
 
-// alpha_e = Minv_e^T (Minv_e y_e) for nexp experts in three launches (u_e, work_e: scratch of n and (n/256) n elements per expert)
+// out[e * eo] = 1/2 y_e^T alpha_e - sum_i log Minv_e[i][i] + n/2 log 2pi: every expert's NLML from its inverse factor's diagonal
+// (log det K = -2 sum log (L^-1)_ii) and its weights, one workgroup per expert
+template <typename T>
+__global__ __launch_bounds__(256) void nlml_batched_kernel(const T* __restrict__ M, long ldm, long eM, const T* __restrict__ y, long ey,
+                                                           const T* __restrict__ alpha, long ea, int n, double* __restrict__ out, long eo) {
+    __shared__ double red[4];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    M += e * eM; y += e * ey; alpha += e * ea;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += 0.5 * (double)y[i] * (double)alpha[i] - log((double)M[(long)i * ldm + i]);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[e * eo] = red[0] + red[1] + red[2] + red[3] + 0.5 * (double)n * 1.83787706640934548356;
+}
+
+// alpha_e = Minv_e^T (Minv_e y_e) for nexp experts in three launches (u_e, work_e: scratch of n and (n/256) n elements per expert);
+// with `out` a fourth launch leaves every expert's NLML at out[e * eo] (n_real points each)
 template <typename T>
 int pg_alpha_batched_t(hipStream_t st, int n, const T* M, long ldm, long eM, const T* y, long ey, T* u, long eu, T* alpha, long ea, T* work,
-                       long ew, int nexp) {
+                       long ew, int nexp, int n_real, double* out, long eo) {
     if (n <= 0 || n % PG_PAD || nexp < 1) { pg_set_error("pg_alpha_batched: n=%d (multiple of %d), nexp=%d", n, PG_PAD, nexp); return -2; }
     hipLaunchKernelGGL(trmv_n_kernel<T>, dim3((n + 15) / 16, 1, nexp), dim3(256), 0, st, M, ldm, n, y, u, eM, ey, eu);
     hipLaunchKernelGGL(gemv_t_partial_kernel<T>, dim3(n / 256, n / 256, nexp), dim3(256), 0, st, M, ldm, (const T*)u, work, (long)n, 1, eM, eu, ew);
     hipLaunchKernelGGL(colreduce_kernel<T>, dim3(n / 256, 1, nexp), dim3(256), 0, st, (const T*)work, (long)n, n / 256, n, alpha, 1, 0.0, 1.0, 0, ew, ea);
+    if (out) hipLaunchKernelGGL(nlml_batched_kernel<T>, dim3(nexp), dim3(256), 0, st, M, ldm, eM, y, ey, (const T*)alpha, ea, n_real, out, eo);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1180,11 +1199,11 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
     template int pg_potrf_t<T>(pg_ctx*, hipStream_t, int, T*, long, T*, int*, T*, long, const BuildReq<T>*, const ExpBatch*, int, int); \
     template int pg_potrs_vec_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, const T*, T*, T*);             \
     template int pg_trtri_t<T>(pg_ctx*, hipStream_t, int, const T*, long, const T*, T*, long, int, const ExpBatch*);       \
-    template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long);                                   \
+    template int pg_lauum_t<T>(pg_ctx*, hipStream_t, int, const T*, long, T*, long, const ExpBatch*);                  \
     template int pg_potrs_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, const T*, long, const T*, long, T*, long, T*, int); \
     template int pg_logdet_t<T>(hipStream_t, int, const T*, long, double*);                                   \
     template int pg_trmv_t<T>(pg_ctx*, hipStream_t, int, const T*, long, int, const T*, T*, T*);                       \
-    template int pg_alpha_batched_t<T>(hipStream_t, int, const T*, long, long, const T*, long, T*, long, T*, long, T*, long, int); \
+    template int pg_alpha_batched_t<T>(hipStream_t, int, const T*, long, long, const T*, long, T*, long, T*, long, T*, long, int, int, double*, long); \
     template int pg_alpha_nlml_async_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, T*, T*, double*); \
     template int pg_nlml_value_t<T>(hipStream_t, int, const T*, long, const T*, const T*, double*);                    \
     template int pg_predict_mean_q_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \

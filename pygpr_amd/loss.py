@@ -9,6 +9,7 @@ one evaluation is: covariance build (lower tiles) -> blocked Cholesky -> L^-1 ->
 point tiles -- n^3 flop in MFMA GEMMs, two n x n device buffers, one [1 + nhp] transfer back.
 `MLE.*` take and return host NumPy fp64 exactly like the reference (scipy drives them).
 """
+import os
 from typing import Tuple
 
 import numpy as np
@@ -17,7 +18,7 @@ from numpy import ndarray
 
 from ._ops import get_ops
 from .covar import layout, spec_of
-from .gpr import GPR, _checked, _lin_alg_error
+from .gpr import _BATCH_EAGER_N, _BATCH_MAX_N, GPR, _checked, _lin_alg_error
 
 
 class Loss():
@@ -45,6 +46,8 @@ class MLE(Loss):
     def __init__(self, model: GPR) -> None:
         super().__init__(model)
         self._buf = {}
+        self._bbuf = {}
+        self.last_batched = False   # the last device evaluation took the experts-together path (tests / diagnostics)
         self.memoize = True     # re-use the last evaluation when asked again at identical parameters (off in benchmarks)
         self._memo = None
         self._factor_key = None   # memo key of the loss-only evaluation whose factor is still in the work buffers
@@ -107,6 +110,44 @@ class MLE(Loss):
         infos = torch.zeros(nb, dtype=torch.int32, device=ops.device)
         res = [None]
 
+        # Experts together (round 4): the reference evaluates a batched model's NLML and gradient as ONE batched factorisation and
+        # solve (loss.py:92-128 on x [nc, n, d] of gr_bcm.py:19-29).  Up to _BATCH_MAX_N points per expert every step below is one
+        # call whose launches cover all experts: build + Cholesky + L^-1, alpha + NLML, K^-1 = L^-T L^-1, the contraction -- about
+        # twenty launches and one synchronisation for the whole batch, where the loop below pays each expert's latency-bound chain
+        # in turn (n = 4096: 0.21 of the matrix peak per expert).  Per expert the numbers are those of the loop on the classic chain.
+        n_pad = experts[0].n_pad
+        self.last_batched = False
+        one_pass = not isinstance(spec, (list, tuple)) or len(spec) == 1
+        batched_path = (nb > 1 and not reuse_factor and one_pass and n_pad <= _BATCH_MAX_N
+                        and (want_grad or n_pad <= _BATCH_EAGER_N) and not os.environ.get("PG_MLE_SERIAL"))
+
+        def enqueue_batched():
+            n = experts[0].n
+            key = ("bat", nb, n_pad, model.dtype, nhp, n)
+            if self._bbuf.get("key") != key:
+                self._bbuf = {
+                    "key": key,
+                    "a": ops.empty(nb, n_pad, n_pad, dtype=model.dtype),       # K -> L -> K^-1, per expert
+                    "m": ops.empty(nb, n_pad, n_pad, dtype=model.dtype),       # L^-1
+                    "invd": ops.empty(nb, ops.potrf_worksize(n_pad, model.dtype), dtype=model.dtype),
+                    "alpha": ops.empty(nb, n_pad, dtype=model.dtype),
+                    "u": ops.empty(nb, n_pad, dtype=model.dtype),
+                    "vwork": ops.empty(nb, (n_pad // 256) * n_pad, dtype=model.dtype),
+                    "gwork": ops.empty(nb * ops.nlml_grad_worksize(n, nhp), dtype=torch.float64) if want_grad else None,
+                }
+            b = self._bbuf
+            if want_grad and b["gwork"] is None:
+                b["gwork"] = ops.empty(nb * ops.nlml_grad_worksize(n, nhp), dtype=torch.float64)
+            x_all, y_all = model._x_all, model._y_all
+            x_stride = x_all.stride(0) if x_all.shape[0] > 1 else 0
+            ops.build_factor_batched(spec, hp_all, x_all, x_stride, b["a"], b["invd"], infos, b["m"])
+            ops.alpha_nlml_batched(b["m"], y_all, b["u"], b["alpha"], b["vwork"], n, outs)
+            if want_grad:
+                ops.lauum_batched(b["m"], b["a"])
+                ops.nlml_grad_batched(spec, hp_all, x_all, x_stride, n, b["a"], b["alpha"], outs[:, 1:], b["gwork"])
+            self.last_batched = True
+            res[0] = outs.cpu().numpy()                                     # the one sync + transfer
+
         def enqueue():
             for b in range(nb):
                 e = experts[b % len(experts)]
@@ -137,7 +178,7 @@ class MLE(Loss):
 
         # (a timed-out coupled chain -- info = -1 -- repeats the evaluation on the classic chain; the re-used factor of a
         # loss-only evaluation was checked when it was made, so that branch cannot time out)
-        for info in _checked(enqueue, lambda: infos.tolist()):
+        for info in _checked(enqueue_batched if batched_path else enqueue, lambda: infos.tolist()):
             if info:
                 raise _lin_alg_error(info)
         losses = res[0][:, 0].copy()

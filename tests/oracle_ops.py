@@ -120,6 +120,26 @@ class OracleOps:
     def potrf_worksize(self, n_pad, dtype):
         return n_pad * NB
 
+    # the experts-together gradient path (MLE on a batched model): per expert through the single-expert doubles
+    def alpha_nlml_batched(self, minv_all, y_all, u_all, alpha_all, work_all, n, out_all):
+        for e in range(minv_all.shape[0]):
+            y = y_all[e % y_all.shape[0]]
+            self.trmv(minv_all[e], y, u_all[e], 0)
+            self.trmv(minv_all[e], u_all[e], alpha_all[e], 1)
+            d = np.diag(_np(minv_all[e]).astype(np.float64))[:n]
+            out_all[e, 0] = 0.5 * float(_np(y)[:n].astype(np.float64) @ _np(alpha_all[e])[:n].astype(np.float64)) \
+                - float(np.log(d).sum()) + 0.5 * n * np.log(2 * np.pi)
+
+    def lauum_batched(self, minv_all, kinv_all):
+        for e in range(minv_all.shape[0]):
+            self.lauum(minv_all[e], kinv_all[e])
+
+    def nlml_grad_batched(self, spec, hp_all, x_all, x_stride, n, kinv_all, alpha_all, grad_all, work):
+        for e in range(kinv_all.shape[0]):
+            g = torch.zeros(hp_all.shape[-1], dtype=torch.float64)
+            self.nlml_grad(spec, hp_all[e], x_all[e if x_stride else 0], n, kinv_all[e], alpha_all[e], g, None)
+            grad_all[e, : g.numel()] = g
+
     def build_factor_batched(self, spec, hp_all, x_all, x_stride, a_all, invd_all, info_all, minv_all=None, jitter=1e-7):
         for e in range(a_all.shape[0]):
             self.build_factor(spec, hp_all[e], x_all[e if x_stride else 0], a_all[e], invd_all[e], info_all[e: e + 1],

@@ -732,9 +732,23 @@ def test_reference_test_sizes_batched(golden):
     np.testing.assert_allclose(N(mu), r["sm_mu"], atol=1e-10)
     np.testing.assert_allclose(N(var), r["sm_var"], atol=1e-11)
     np.testing.assert_allclose(N(gp.wt), r["sm_wt"], rtol=1e-9, atol=1e-9)
-    loss, grad = pg.MLE(gp).loss_and_grad(r["sm_hp"].copy())
+    mle = pg.MLE(gp)
+    loss, grad = mle.loss_and_grad(r["sm_hp"].copy())
+    assert mle.last_batched                              # round 4: the gradient path ran experts-together too (one sync, ~20 launches)
     np.testing.assert_allclose(loss, r["sm_loss"], rtol=1e-10)
     np.testing.assert_allclose(grad, r["sm_grad"], rtol=1e-8, atol=1e-8 * np.abs(r["sm_grad"]).max())
+    mle.memoize = False
+    os.environ["PG_MLE_SERIAL"] = "1"                    # the per-expert loop of rounds 1-3: same numbers to rounding
+    try:
+        loss1, grad1 = mle.loss_and_grad(r["sm_hp"].copy())
+    finally:
+        del os.environ["PG_MLE_SERIAL"]
+    assert not mle.last_batched
+    np.testing.assert_allclose(loss, loss1, rtol=1e-12)
+    np.testing.assert_allclose(grad, grad1, rtol=1e-9, atol=1e-10 * np.abs(grad1).max())
+    lo = mle.loss(r["sm_hp"].copy())                     # loss only, batched as well (n <= 4096: through the inverse factors)
+    assert mle.last_batched
+    np.testing.assert_allclose(lo, r["sm_loss"], rtol=1e-10)
     nc = r["sg_xl"].shape[0]
     g = pg.GRBCM(T(r["sg_xl"]), T(r["sg_yl"]), T(r["sg_xg"]), T(r["sg_yg"]), se_wn())
     g.set_params(T(r["sg_hp"]))
