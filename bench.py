@@ -278,6 +278,21 @@ def main():
             rep["per_rank"] = every
         return rep
 
+    def allreduce_us(nwords, reps=50):
+        """Latency of one all-reduce(sum) of nwords doubles, max over ranks (0.0 on one rank)."""
+        if world == 1:
+            return 0.0
+        buf = torch.zeros(nwords, dtype=torch.float64, device=cdev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        sync()
+        dist.barrier()
+        t0_ = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        sync()
+        return 1e6 * max_over_ranks((time.perf_counter() - t0_) / reps)
+
     if args.rendezvous_only:
         rep = dist_report(1 + (args.d + 2) + world)
         if rank == 0:
@@ -533,6 +548,68 @@ def main():
             out["gpu_over_cpu"] = value / world / out["cpu_baseline"]["value"]
             out["cpu_baseline_as_written"] = cpu_baseline_as_written(n, d, min(args.cpu_n_written, n))
 
+    if legs:
+        # ---- BASELINE config 3 as stated: "hp_update/opt.py: 50 NLML-grad steps" through the optimiser -- scipy's CG driving
+        # MLE.loss_and_grad (PyGPR/opt.py:45-67) with maxiter = 50 at N = 16384 on this build: evaluations, seconds, and the cost of
+        # one evaluation INCLUDING scipy's line-search logic and the host round trip of hp / [1 + nhp] per call
+        import tempfile
+        cwd = os.getcwd()
+        os.chdir(tempfile.mkdtemp())            # CG writes its trace file where it runs (opt.py:66)
+        try:
+            gp3 = pg.Exact_GP(model.gpl._x[0], model.gpl._y[0], cov)
+            gp3.set_params(torch.from_numpy(hp))
+            mle3 = pg.MLE(gp3)
+            mle3.memoize = False
+            nlml0 = float(mle3.loss(hp.copy()))
+            cg = pg.CG(mle3)
+            cg.args.update(maxiter=50, disp=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # the driver prints "Optimizer Failed" at maxiter like the reference (opt.py:63);
+                cg.minimize()                                 # stdout carries the ONE JSON line
+            torch.cuda.synchronize()
+            tcg = time.perf_counter() - t0
+            nlml1 = float(cg.res.fun)
+            assert nlml1 < nlml0, "CG did not decrease the NLML: %r -> %r" % (nlml0, nlml1)
+            out["cfg3_cg_run"] = {
+                "config": "pg.CG(pg.MLE(Exact_GP)).minimize(), maxiter = 50, N = %d D = %d, start hp sigma = 1 l = 1 sigma_n = 0.1" % (n, d),
+                "iterations": int(cg.res.nit), "evaluations": int(cg.res.nfev), "seconds": tcg, "ms_per_evaluation": 1e3 * tcg / max(int(cg.res.nfev), 1),
+                "evals_per_s": int(cg.res.nfev) / tcg, "nlml_start": nlml0, "nlml_end": nlml1, "scipy_success": bool(cg.res.success),
+                "note": "every evaluation is a full NLML + gradient (memo off); ms_per_evaluation includes scipy and the host round trip",
+            }
+            del gp3, mle3, cg
+        finally:
+            os.chdir(cwd)
+        torch.cuda.empty_cache()
+        # ---- row f-1: the full predictive covariance (gpr.py:108-120) at config 2's size: K* build, V = L^-1 K* (n^2 m flop, K
+        # ranges), C = K** - V^T V (n m^2 flop on lower tiles, mirrored afterwards)
+        x2f, y2f = synth_expert(8192, d, 4242)
+        gpf = pg.Exact_GP(torch.from_numpy(x2f), torch.from_numpy(y2f), cov, eager_inverse=True)
+        gpf.set_params(torch.from_numpy(hp))
+        mf = 4096
+        xsf = torch.from_numpy(np.random.default_rng(11).random((mf, d))).cuda()
+        gpf.update()
+        gpf.predict(xsf, var="full")
+        torch.cuda.synchronize()
+        tf_ = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            muf, covf = gpf.predict(xsf, var="full")
+            torch.cuda.synchronize()
+            tf_ = min(tf_, time.perf_counter() - t0)
+        flopf = float(8192) ** 2 * mf + 8192.0 * float(mf) ** 2
+        out["predict_full"] = {
+            "config": "Exact_GP.predict(var='full'), n = 8192, D = %d, m = %d test points (factor and L^-1 resident)" % (d, mf),
+            "ms": 1e3 * tf_, "points_per_s": mf / tf_, "cov_diag_mean": float(torch.diagonal(covf).mean()), "cov_symmetric": bool(torch.equal(covf, covf.T)),
+            "roofline": {"bound": "mfma", "achieved": flopf / tf_ / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flopf / tf_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "algorithmic_flops": flopf,
+                         "kernel": "pg_gemm_kernel<double, NN, 128x128> (V = L^-1 K*, K ranges) + <double, TN, 128x128> (K** - V^T V, lower tiles)",
+                         "note": "flop = n^2 m (triangular product) + n m^2 (symmetric update); the K* / K** builds and the mirror are HBM-bound extras inside the time"},
+        }
+        del gpf, xsf, muf, covf
+        torch.cuda.empty_cache()
+
     # ---- secondary metric: grBCM committee prediction throughput (BASELINE config 4)
     del model, loss, local, exp
     torch.cuda.empty_cache()
@@ -567,6 +644,7 @@ def main():
             "config": "8 experts x (%d global + %d local) points, D=%d, RBF+noise fp64, %d test points in batches of %d, "
                       "diag variance; experts sharded over %d rank(s); one [3,m] all-reduce per batch" % (ng4, nls4, d4, m4, mb, world),
             "mean_abs": float(mu.abs().mean()), "var_mean": float(var.mean()),
+            "allreduce_us_per_batch": allreduce_us(3 * mb + world), "allreduce_doubles_per_batch": 3 * mb + world, "batches": m4 // mb,
             "roofline": {"bound": "mfma", "achieved": flop4 / tp / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": flop4 / tp / 1e12 / (FP64_MATRIX_PEAK_TFLOPS * world), "algorithmic_flops": flop4,
                          "kernel": "pg_gemm_kernel<double,...> column-sum epilogue (variance product L^-1 K*^T), all experts",
@@ -613,6 +691,42 @@ def main():
             tb_, ts_ = fit_ms(nc_, n_, d_, True), fit_ms(nc_, n_, d_, False)
             et[name] = {"batched_ms": tb_, "one_after_the_other_ms": ts_, "speedup": ts_ / tb_,
                         "tflops_batched": nc_ * 2.0 * float(n_) ** 3 / 3.0 / (tb_ * 1e-3) / 1e12}
+        # the gradient path experts-together (round 4): MLE.loss_and_grad on a batched model, params [nc, nhp] (loss.py:92-128 of the
+        # reference on x [nc, n, d]) -- one batched call per step (build + factor + L^-1, alpha + NLML, K^-1, contraction) and ONE
+        # synchronisation, against the per-expert loop of rounds 1-3 (PG_MLE_SERIAL=1)
+        def mle_ms(nc_, n_, d_, batched):
+            rng_ = np.random.default_rng(3)
+            x_ = rng_.random((nc_, n_, d_))
+            y_ = np.sin(-x_.sum(-1)) + 0.1 * rng_.standard_normal((nc_, n_))
+            gp_ = pg.Exact_GP(torch.from_numpy(x_), torch.from_numpy(y_), cov)
+            hp_ = np.tile(np.concatenate([[1.0], np.full(d_, 0.5), [0.1]]), (nc_, 1))
+            mle_ = pg.MLE(gp_)
+            mle_.memoize = False
+            if not batched:
+                os.environ["PG_MLE_SERIAL"] = "1"
+            try:
+                l_, g_ = mle_.loss_and_grad(hp_.copy())
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(3):
+                    t0_ = time.perf_counter()
+                    mle_.loss_and_grad(hp_.copy())
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0_)
+                assert mle_.last_batched == batched
+            finally:
+                os.environ.pop("PG_MLE_SERIAL", None)
+            del gp_, mle_
+            torch.cuda.empty_cache()
+            return 1e3 * best, l_, g_
+
+        for name, (nc_, n_, d_) in (("mle_nc10_n100", (10, 100, 3)), ("mle_nc8_n2048", (8, 2048, 16)), ("mle_nc8_n4096", (8, 4096, 16))):
+            (tb_, lb_, gb_), (ts_, ls_, gs_) = mle_ms(nc_, n_, d_, True), mle_ms(nc_, n_, d_, False)
+            assert np.allclose(lb_, ls_, rtol=1e-10) and np.allclose(gb_, gs_, rtol=1e-7, atol=1e-9 * np.abs(gs_).max())
+            et[name] = {"batched_ms": tb_, "one_after_the_other_ms": ts_, "speedup": ts_ / tb_,
+                        "tflops_batched": nc_ * float(n_) ** 3 / (tb_ * 1e-3) / 1e12, "synchronisations": 1,
+                        "what": "MLE.loss_and_grad, params [nc, nhp]: n^3 flop per expert (factor + L^-1 + K^-1); batched and looped "
+                                "results agree (asserted: NLML 1e-10, gradient 1e-7)"}
         et["what"] = ("Exact_GP.update(), eager inverse: covariance build + Cholesky + L^-1 + alpha for nc experts of n points, best of 3; "
                       "batched = pg_build_potrf_trtri_batched + pg_alpha_batched (every launch covers all experts)")
         out["experts_together"] = et
@@ -648,6 +762,44 @@ def main():
             "dtype": "f32", "ms_per_eval": 1e3 * t5, "ms_per_expert": 1e3 * t5 / nc5, "evals_per_s": 1.0 / t5,
             "tflops": flop5 / t5 / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "frac_of_fp32_matrix_peak": flop5 / t5 / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
             "algorithmic_flops_per_eval": flop5, "loss": float(l5), "grad_inf": float(np.abs(g5).max()),
+        }
+        del m5, obj5
+
+    # ---- BASELINE config 5 in its stated layout (world > 1): ONE fp32 Matern-5/2 expert of 1024 + 32768 points per GPU, shared-hp
+    # co-training objective, one all-reduce of [1 + nhp] + world status words per evaluation (GRBCM_MLE).  1 warm-up + 3 evaluations.
+    if world > 1 and not args.no_legs:
+        torch.cuda.empty_cache()
+        nls5, ng5, d5 = 32768, 1024, 16
+        rng = np.random.default_rng(1234)
+        f5 = lambda x: np.sin(-x.sum(-1)) + 0.1 * rng.standard_normal(x.shape[:-1])   # noqa: E731
+        xl5 = rng.random((world, nls5, d5)); yl5 = f5(xl5)
+        xg5 = rng.random((ng5, d5)); yg5 = f5(xg5)
+        t32 = lambda a: torch.from_numpy(a).to(torch.float32)   # noqa: E731
+        m5 = pg.GRBCM(t32(xl5), t32(yl5), t32(xg5), t32(yg5), pg.Compose([pg.Matern52(), pg.White_noise()]), distributed=True)
+        obj5 = pg.GRBCM_MLE(m5)
+        obj5.memoize = False
+        hp5 = np.concatenate([[1.0], 0.5 * np.ones(d5), [0.1]])
+        obj5.loss_and_grad(hp5.copy())
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(3):
+            l5, g5 = obj5.loss_and_grad(hp5 * (1.0 + 1e-3 * (i + 1)))
+        torch.cuda.synchronize()
+        t5_local = (time.perf_counter() - t0) / 3
+        barrier()
+        t5 = max_over_ranks((time.perf_counter() - t0) / 3)
+        every5 = [None] * world
+        dist.all_gather_object(every5, float(t5_local))
+        n5 = ng5 + nls5
+        flop5 = world * float(n5) ** 3
+        out["cfg5_cotrain"] = {
+            "config": "grBCM co-training objective, ONE expert of (%d global + %d own) = %d points per GPU on %d GPUs, D=%d, Matern-5/2 + "
+                      "noise, fp32, shared hp; 1 warm-up + 3 evaluations of sum_c NLML_c and its gradient, one all-reduce each"
+                      % (ng5, nls5, n5, world, d5),
+            "dtype": "f32", "scaling": "weak", "ms_per_eval": 1e3 * t5, "evals_per_s": 1.0 / t5, "ms_per_eval_per_rank": [1e3 * v for v in every5],
+            "tflops": flop5 / t5 / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS * world, "frac_of_fp32_matrix_peak": flop5 / t5 / 1e12 / (FP32_MATRIX_PEAK_TFLOPS * world),
+            "algorithmic_flops_per_eval": flop5, "loss": float(l5), "grad_inf": float(np.abs(g5).max()),
+            "allreduce_us": allreduce_us(1 + (d5 + 2) + world), "allreduce_doubles": 1 + (d5 + 2) + world,
         }
         del m5, obj5
 

@@ -4,7 +4,8 @@
 `predict` = K* build, mean K* alpha, and either the diagonal predictive variance
 diag(K**) - rowsum(K* o (K^-1 K*^T)^T) (gpr.py:96-106) or the full covariance (gpr.py:108-120).
 All state lives on the GPU in padded buffers (n rounded up to 256, identity in the padding); the
-leading expert dimension of the reference's batched models is a host loop over per-expert buffers.
+leading expert dimension of the reference's batched models lives in stacked tensors (`_batch`): factorisation, inverse and
+weights of all experts are one batched call; prediction walks the experts.
 
 Differences a caller can observe:
   * the triangular solves against K* use the explicit inverse factor L^-1 (cached per update), so the
@@ -362,7 +363,8 @@ class Exact_GP(GPR):
         ops.trmm_lower(self._minv(e), ks, v)
         c = ops.empty(m_pad, m_pad, dtype=self.dtype)
         ops.kernel_build(spec, e.hp, xpd, None, c)      # K** incl. sigma_n^2, padding = identity
-        ops.syrk_tn_sub(v, c, lower_only=False)
+        ops.syrk_tn_sub(v, c, lower_only=True)          # n m^2 flop on the lower tiles (round 4; the full square was twice that),
+        ops.symmetrize(c, m_pad)                        # the upper triangle is the mirror: exactly symmetric, as before
         return c[:m, :m]
 
     def _predict_device(self, xpd, want):
