@@ -99,7 +99,9 @@ def _run_and_check(tmp_path, golden, world, cases):
 
 
 def test_grbcm_two_ranks_gloo(tmp_path, golden):
-    _run_and_check(tmp_path, golden, 2, (0, 1, 2))
+    """2 ranks: nc = 2 (1 each), 4 (2 each), 8 (2 x 4: the third layout of the scaling curve)."""
+    outs = _run_and_check(tmp_path, golden, 2, (0, 1, 2))
+    assert [int(o["nloc2"]) for o in outs] == [4, 4]
 
 
 def test_grbcm_three_ranks_uneven_blocks_and_an_empty_rank(tmp_path, golden):
@@ -109,6 +111,20 @@ def test_grbcm_three_ranks_uneven_blocks_and_an_empty_rank(tmp_path, golden):
     outs = _run_and_check(tmp_path, golden, 3, (0, 2))
     assert [int(o["nloc0"]) for o in outs] == [1, 1, 0] and [int(o["nloc2"]) for o in outs] == [3, 3, 2]
     assert int(outs[0]["owner"]) == 1
+
+
+def test_grbcm_eight_ranks_one_expert_each(tmp_path, golden):
+    """The layout north_star names: 8 ranks x 1 expert (nc = 8) -- diag and full-covariance committee and the shared-hp objective
+    end on every rank with the single-process golden answer; in the failing-expert part (nc = 4 on 8 ranks) four ranks own no
+    expert at all and the owner is rank 3."""
+    outs = _run_and_check(tmp_path, golden, 8, (2,))
+    assert [int(o["nloc2"]) for o in outs] == [1] * 8 and int(outs[0]["owner"]) == 3
+
+
+def test_grbcm_four_ranks_two_experts_each(tmp_path, golden):
+    """4 ranks x 2 experts (nc = 8: each rank's local experts take the experts-together path of Exact_GP / MLE) and 4 x 1 (nc = 4)."""
+    outs = _run_and_check(tmp_path, golden, 4, (2, 1))
+    assert [int(o["nloc2"]) for o in outs] == [2] * 4 and [int(o["nloc1"]) for o in outs] == [1] * 4
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
