@@ -465,6 +465,8 @@ def main():
             "frac": bytes_build / t_build / 1e6 / HBM_PEAK_GBS, "ms": t_build, "algorithmic_bytes": bytes_build,
             "kernel": "pg_kbuild_kernel<double, true, 2> (mirrored symmetric build); lower_only: <double, false, 2>, the build the "
                       "factorisation's path uses", "timing": "HIP events around 4 back-to-back launches / 4, best of 5",
+            "method_changed_since": "r02 (one launch per event pair there: about 70 us of launch latency on top of the kernel; the "
+                                    "single-launch figure of this run is lower_only.ms_single_launch)",
         }
         t_lower = timed(lambda: build_x4(True), 5) / 4
         bytes_lower = 4.0 * n * (n + 64) + 8.0 * n * d
@@ -480,6 +482,7 @@ def main():
                 out["roofline_kernel_build"]["lower_only"]["traffic"] = kj["lower_only"]["hbm_bytes_pmc"]
                 out["roofline_kernel_build"]["traffic_source"] = "profiles/r03_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
         t_lower_single = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)   # one launch, for the legs below
+        out["roofline_kernel_build"]["lower_only"]["ms_single_launch"] = t_lower_single
 
         def fac():
             ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7)

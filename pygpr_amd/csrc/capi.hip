@@ -110,7 +110,9 @@ static int plain_device_memory(const void* p) {
         (void)hipGetLastError();
         return 0;
     }
-    return a.type == hipMemoryTypeDevice && !a.isManaged;
+    // (fine-grained device allocations -- hipExtMallocWithFlags(hipDeviceMallocFinegrained) -- also report hipMemoryTypeDevice: they are
+    //  exactly the memory where memory-side fp64 atomics may be dropped)
+    return a.type == hipMemoryTypeDevice && !a.isManaged && !(a.allocationFlags & hipDeviceMallocFinegrained);
 }
 struct AtomicGuard {
     pg_ctx* h;
@@ -847,8 +849,8 @@ int pg_rowstep_raw(pg_handle h, int dtype, int n, void* A, long lda, int o0, int
     PG_CHECK(hipMemsetAsync(flags, 0x40, 8 * sizeof(int), ST(stream)));
     PG_CHECK(hipMemsetAsync(flags + 6, 0, 2 * sizeof(int), ST(stream)));   // [6]: time-out word, [7]: spare
     const CsWait cw = {flags + 6, nullptr, 200000000LL, 1};
-    DISPATCH(dtype, pg_rowstep<double>(ST(stream), (double*)A, lda, n, o0, k0, 1, (const double*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4),
-             pg_rowstep<float>(ST(stream), (float*)A, lda, n, o0, k0, 1, (const float*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4));
+    DISPATCH(dtype, pg_rowstep<double>(ST(stream), (double*)A, lda, n, o0, k0, 1, (const double*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4, 0),
+             pg_rowstep<float>(ST(stream), (float*)A, lda, n, o0, k0, 1, (const float*)inv, flags, flags + 1, flags + 2, cw, info, flags + 3, flags + 4, 0));
 }
 
 int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double alpha, const void* A, long lda,

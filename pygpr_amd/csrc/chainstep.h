@@ -43,6 +43,6 @@ __device__ __forceinline__ bool cs_spin_ge(int* flag, int want, const CsWait& w)
 }
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, const CsWait& wt, int* info, int* early_k = nullptr, int* browe_k = nullptr);   // early_k: two-phase hand-over
+               int* diag_next, const CsWait& wt, int* info, int* early_k = nullptr, int* browe_k = nullptr, int allow_tlog = 1);   // early_k: two-phase hand-over
 int pg_flagset(hipStream_t st, int* flag, int value);
 int pg_spin_probe_launch(hipStream_t st, int* flag, const CsWait& w, long long* out);   // tests: one bounded wait on a flag nobody sets

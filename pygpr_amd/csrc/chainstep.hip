@@ -391,7 +391,7 @@ __global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(fla
 
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, const CsWait& tmo, int* info, int* early_k, int* browe_k) {
+               int* diag_next, const CsWait& tmo, int* info, int* early_k, int* browe_k, int allow_tlog) {
     const int m = n - k0 - NB;
     if (m <= 0 || m % NB) { pg_set_error("pg_rowstep: %d rows below the tile", m); return -2; }
     const size_t lds = (size_t)(32 * CS_XLD + 32 * CS_CLD + NB * CS_CLD) * sizeof(T);
@@ -407,13 +407,15 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
     const int rows16 = (rows16_env > 0 && m <= rows16_env) ? (rows16_direct ? 2 : 1) : 0;
     hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / (rows16 ? 16 : 32)), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
-                       getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr, direct ? early_k : nullptr,
+                       // (the in-kernel time log lives behind the flag words of a factorisation's work buffer: never for a caller that
+                       //  brings its own small flag array, pg_rowstep_raw)
+                       (allow_tlog && getenv("PG_CS_TLOG")) ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr, direct ? early_k : nullptr,
                        browe_k, rows16);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*, int*, int*);
-template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*, int*, int*);
+template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*, int*, int*, int);
+template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*, int*, int*, int);
 
 int pg_flagset(hipStream_t st, int* flag, int value) {
     hipLaunchKernelGGL(pg_flagset_kernel, dim3(1), dim3(1), 0, st, flag, value);

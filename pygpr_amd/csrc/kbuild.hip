@@ -189,10 +189,19 @@ __device__ __forceinline__ void kb_body(const pg_covspec& spec, const T* xr, con
 #pragma unroll
                 for (int c = 0; c < 4; ++c) arg[r][c] += a[r] * b[c];
         }
+        // The expansion's absolute error is eps |x l|^2, not relative to the distance: near-duplicate points can come out with a slightly
+        // POSITIVE argument (K_ij > sigma^2) and, in a symmetric build, the diagonal off sigma^2 by that error.  One v_min per element
+        // keeps K_ij <= sigma^2; tiles on the diagonal take the exact 0 where a point meets itself (a NaN argument stays NaN).
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[r][c] = (T)pg_exp_tab((double)arg[r][c], tab);
+            for (int c = 0; c < 4; ++c) {
+                T a = arg[r][c] > (T)0 ? (T)0 : arg[r][c];
+                if (CHECKED) {
+                    if (symmetric && tr == tc && ty * 4 + r == (c / VE) * (16 * VE) + tx * VE + (c % VE) && a == a) a = (T)0;
+                }
+                out[r][c] = (T)pg_exp_tab((double)a, tab);
+            }
     }
     for (int cp = 0; cp < (FAST ? 0 : spec.ncomp); ++cp) {
         const T* lc = l2 + cp * d;

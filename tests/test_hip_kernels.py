@@ -292,6 +292,33 @@ def test_kernel_build_propagates_nan(ops):
         assert int(info.item()) == 24            # LAPACK convention: the leading minor of order 24
 
 
+@pytest.mark.parametrize("offset", [0.0, 1.0e3, 1.0e4])
+def test_kernel_build_fast_body_on_uncentred_data(ops, offset):
+    """The fp64 one-squared-exponential build forms the exponent as 2 x.x' - |x|^2 - |x'|^2 (the reference's own expansion,
+    covar.py:102-127): its ABSOLUTE error is eps |x l|^2, whatever the distance.  With the points shifted by 1e3 / 1e4 (|x l|^2 ~ 3e6 /
+    3e8) the covariance must stay within that bound of the direct-difference oracle, never exceed sigma^2 (the argument is clamped at 0:
+    near-duplicate points), and the diagonal of a symmetric build is sigma^2 + sigma_n^2 + jitter EXACTLY; the matrix still factorises."""
+    rng = np.random.default_rng(17)
+    n, d = 700, 3
+    x = rng.random((n, d))
+    x[1] = x[0] + 1e-9                      # a near-duplicate pair
+    x += offset
+    hp = np.array([1.3, 1.0, 0.9, 1.1, 0.05])
+    covs = [orc.SE, orc.WN]
+    k = ops.empty(768, 768)
+    ops.kernel_build(_spec(covs, d), dev(hp), dev(x), None, k, jitter=1e-7)
+    got = host(k)[:n, :n]
+    ref = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    bound = 2.0 ** -52 * 8.0 * (d * (offset + 1.0) ** 2 * 1.21) * 1.69 + 1e-14      # eps x (a few) x |x l|^2 x sigma^2
+    np.testing.assert_allclose(got, ref, atol=bound, rtol=0)
+    diag = 1.3 ** 2 + 0.05 ** 2 + 1e-7
+    assert np.all(np.diag(got) == diag) and got[np.triu_indices(n, 1)].max() <= 1.3 ** 2
+    np.testing.assert_array_equal(got, got.T)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.potrf(k, ops.potrf_workspace(768, torch.float64), info)
+    assert int(info.item()) == 0
+
+
 def test_kernel_build_fp32(ops):
     from pygpr_amd._ops import pad_to
 
