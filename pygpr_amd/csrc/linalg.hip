@@ -431,7 +431,8 @@ int pg_trtri_t(pg_ctx* ctx, hipStream_t st, int n, const T* L, long ldl, const T
             p.sA = stride; p.sC = stride; p.sB = 2 * h * (ldl + 1);
             p.nexp = nexp; p.eA = eMm; p.eB = eL; p.eC = eMm;
             // few pairs of small blocks: 64 x 64 tiles give 4x the workgroups, each a quarter as long (h = 256: 42 -> 15 us)
-            const bool small = batch * (h / 128) * (h2 / 128) <= 1024 && h2 % 64 == 0;   // swept 128 .. 4200
+            // (experts together: the launch carries nexp times the tiles)
+            const bool small = batch * (h / 128) * (h2 / 128) * nexp <= 1024 && h2 % 64 == 0;   // swept 128 .. 4200
             if ((rc = pg_gemm<T>(ctx, st, small ? GEMM_TT_64 : GEMM_TT_128, p))) return rc;
             // X21 = -X22 S^T
             p = gp0<T>();
