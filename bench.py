@@ -406,7 +406,7 @@ def main():
         # from separate rocprofv3 --pmc passes over the same evaluation (tools/probe_eval_once.py, tools/pmc_summary.py),
         # committed under profiles/ together with the identity of the build they were taken on.  A summary taken on
         # another build (kernel sources changed since) is not reported.
-        pmc_name = "r03_pmc_eval_traffic.json"
+        pmc_name = "r04_pmc_eval_traffic.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if n == 16384 and os.path.exists(pmc):
             with open(pmc) as fh:
@@ -453,7 +453,7 @@ def main():
             return best
 
         # the covariance build: FOUR launches back to back between two events, so that the figure is the kernel's duration
-        # (what rocprofv3 --kernel-trace reports: profiles/r03_kernel_build_hbm.json) and not one launch's latency on top of it
+        # (what rocprofv3 --kernel-trace reports: profiles/r04_kernel_build_hbm.json) and not one launch's latency on top of it
         def build_x4(lower):
             for _ in range(4):
                 ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=lower, jitter=1e-7)
@@ -473,14 +473,14 @@ def main():
         out["roofline_kernel_build"]["lower_only"] = {"ms": t_lower, "algorithmic_bytes": bytes_lower,
                                                       "achieved": bytes_lower / t_lower / 1e6,
                                                       "frac": bytes_lower / t_lower / 1e6 / HBM_PEAK_GBS}
-        kbp = os.path.join(ROOT, "profiles", "r03_kernel_build_hbm.json")
+        kbp = os.path.join(ROOT, "profiles", "r04_kernel_build_hbm.json")
         if n == 16384 and os.path.exists(kbp):
             with open(kbp) as fh:
                 kj = json.load(fh)
             if kj.get("build", {}).get("src_sha16") == out["build"]["src_sha16"]:
                 out["roofline_kernel_build"]["traffic"] = kj["mirrored"]["hbm_bytes_pmc"]
                 out["roofline_kernel_build"]["lower_only"]["traffic"] = kj["lower_only"]["hbm_bytes_pmc"]
-                out["roofline_kernel_build"]["traffic_source"] = "profiles/r03_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
+                out["roofline_kernel_build"]["traffic_source"] = "profiles/r04_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
         t_lower_single = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)   # one launch, for the legs below
         out["roofline_kernel_build"]["lower_only"]["ms_single_launch"] = t_lower_single
 

@@ -11,7 +11,7 @@ def load(d, counter):
     last = max(i for i, r in enumerate(rows) if "kbuild" in r["Kernel_Name"] and "grad" not in r["Kernel_Name"])
     return rows[last:]
 def group(name):
-    if "pg_gemm_kernel" in name: return "gemm_core"
+    if "pg_gemm_kernel" in name or "pg_gemm_mixed_kernel" in name: return "gemm_core"
     m = re.search(r"(pg_\w+|\w+_kernel)", name)
     return m.group(1) if m else name[:30]
 out = {}

@@ -1,11 +1,17 @@
 cd /tmp && export TMPDIR=/tmp
-RD=${PG_ROUND:-r03}
+RD=${PG_ROUND:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$RD; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench.log 2>&1; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss -- python3 $R/tools/probe_eval_single_stream.py > $O/ss.log 2>&1; echo "ss rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 $R/tools/probe_eval_once.py > $O/pmc_f.log 2>&1; echo "pmc_f rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 $R/tools/probe_eval_once.py > $O/pmc_w.log 2>&1; echo "pmc_w rc=$?"
 python3 $R/tools/pmc_summary.py $O/pmc_f $O/pmc_w > $O/${RD}_pmc_eval_traffic.json; echo "summary rc=$?"
+# MFMA counters (north_star: MFMA utilisation from rocprof): the factorisation and L^-T L^-1 at N = 16384, each its own pass
+for w in potrf lauum; do
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_$w -- python3 $R/tools/probe_mfma_pass.py $w > $O/mfma_$w.log 2>&1; echo "mfma $w rc=$?"
+  python3 $R/tools/pmc_mfma_summary.py $O/mfma_$w $w > $O/${RD}_pmc_mfma_$w.json; echo "mfma $w summary rc=$?"
+done
+rm -rf $O/mfma_potrf $O/mfma_lauum
 PG_NO_PY_ATEXIT=1 rocprofv3 --kernel-trace --output-format csv -d $O/teardown -- python3 $R/tools/probe_potrf.py 8192 potrf_only > $O/teardown.log 2>&1; echo "teardown rc=$?"
 f=$(find $O/bench -name "*kernel_stats.csv" | head -1); cp $f $O/${RD}_kernel_stats_bench.csv; python3 $R/tools/stats_summary.py $f > $O/${RD}_kernel_stats_bench.txt
 f=$(find $O/ss -name "*kernel_stats.csv" | head -1); cp $f $O/${RD}_kernel_stats_ss.csv; python3 $R/tools/stats_summary.py $f > $O/${RD}_kernel_stats_ss.txt
@@ -22,3 +28,11 @@ python3 $R/tools/probe_cs_tlog.py 8192 > $O/${RD}_potrf_chain_timeline_n8192.txt
 # the leaf's 16 x 16 factor, old form against blocked form, in isolation; the rows kernel alone
 $R/tools/micro/blockfac > $O/${RD}_leaf_factor_micro.txt 2>&1; echo "blockfac rc=$?"
 python3 $R/tools/probe_rowstep.py > $O/${RD}_rows_kernel_alone.txt 2>&1; echo "rowstep rc=$?"
+# the evaluation's wall time by phase (headline schedule) and the N = 8192 factorisation's queues
+rocprofv3 --kernel-trace --output-format csv -d $O/ev -- python3 $R/tools/probe_eval_loop.py 4 > $O/ev.log 2>&1; echo "eval loop rc=$?"
+f=$(find $O/ev -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_eval_gaps.py $f > $O/${RD}_eval_phases.txt; rm -rf $O/ev
+PG_REC_MIN=0 rocprofv3 --kernel-trace --output-format csv -d $O/p8 -- python3 $R/tools/probe_potrf_trace.py plain 8192 > $O/p8.log 2>&1; echo "potrf trace rc=$?"
+f=$(find $O/p8 -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_chain.py $f 3 > $O/${RD}_potrf_kernel_trace_n8192.txt; rm -rf $O/p8
+python3 $R/tools/probe_tri_rounds.py 8192 31 32 45 55 63 64 66 > $O/${RD}_tri_rounds_mixed.txt 2>&1; echo "rounds rc=$?"
+PG_GEMM_MIXED=0 python3 $R/tools/probe_tri_rounds.py 8192 31 32 45 55 63 64 66 > $O/${RD}_tri_rounds_plain.txt 2>&1; echo "rounds plain rc=$?"
+python3 $R/tools/probe_big_products.py 0 > $O/${RD}_big_products.txt 2>&1; echo "big products rc=$?"
