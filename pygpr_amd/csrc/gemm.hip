@@ -25,21 +25,34 @@ template <typename T, int R, bool KCONT, int BKT = BK, int NTH = 256> struct Sta
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     typedef T half_t __attribute__((ext_vector_type(VE / 2)));
     vec_t v[NV];
+    unsigned boff[NV];   // this lane's BYTE offsets inside a K tile, relative to the tile's origin (loop invariant)
 
-    __device__ __forceinline__ void load(const T* __restrict__ g, long ld, int r0, int k0, int tid) {
+    // Addressing (round 4): a wave-uniform 64-bit origin (scalar registers, advanced by a scalar add per K tile) plus a 32-bit
+    // per-lane byte offset -- the global_load saddr + voffset form.  With a 64-bit pointer per lane and vector (rounds 1-3) the fp64
+    // 128 x 128 block needed 133 VGPRs: one base pointer was spilled and RELOADED from scratch at the top of every K tile, behind
+    // an `s_waitcnt vmcnt(0)` in front of the tile's loads.  (The offsets stay below 2^32 for every leading dimension the library
+    // can meet: 128 rows x ld x 8 bytes, ld < 4 M elements.)
+    __device__ __forceinline__ void init(long ld, int tid) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int idx = tid + NTH * q;
-            const T* p;
             if (KCONT) {
                 const int row = idx / (BKT / VE), kv = idx % (BKT / VE);
-                p = g + (long)(r0 + row) * ld + k0 + kv * VE;
+                boff[q] = (unsigned)(((long)row * ld + kv * VE) * (long)sizeof(T));
             } else {
                 const int kr = idx / (R / VE), rv = idx % (R / VE);
-                p = g + (long)(k0 + kr) * ld + r0 + rv * VE;
+                boff[q] = (unsigned)(((long)kr * ld + rv * VE) * (long)sizeof(T));
             }
-            v[q] = *reinterpret_cast<const vec_t*>(p);
         }
+    }
+    // origin of the K tile at k0 for the tile rows / columns starting at r0 (wave-uniform)
+    static __device__ __forceinline__ const T* origin(const T* __restrict__ g, long ld, int r0, int k0) {
+        return KCONT ? g + (long)r0 * ld + k0 : g + (long)k0 * ld + r0;
+    }
+    __device__ __forceinline__ void load(const T* __restrict__ org) {
+        const char* b = reinterpret_cast<const char*>(org);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = *reinterpret_cast<const vec_t*>(b + (size_t)boff[q]);
     }
     __device__ __forceinline__ void store(T* s, int tid) const {
 #pragma unroll
@@ -176,10 +189,12 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
 
     SA sa;
     SB sb;
+    sa.init(p.lda, tid);
+    sb.init(p.ldb, tid);
     const int nk = (kend - kbeg) / BKT;
     if (nk > 0) {
-        sa.load(A, p.lda, m0, kbeg, tid);
-        sb.load(B, p.ldb, n0, kbeg, tid);
+        sa.load(SA::origin(A, p.lda, m0, kbeg));
+        sb.load(SB::origin(B, p.ldb, n0, kbeg));
         sa.store(As, tid);
         sb.store(Bs, tid);
     }
@@ -190,8 +205,8 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
         const int cur = kt & 1;
         const int k0 = kbeg + kt * BKT;
         if (kt + 1 < nk) {
-            sa.load(A, p.lda, m0, k0 + BKT, tid);
-            sb.load(B, p.ldb, n0, k0 + BKT, tid);
+            sa.load(SA::origin(A, p.lda, m0, k0 + BKT));
+            sb.load(SB::origin(B, p.ldb, n0, k0 + BKT));
         }
         if (k0 + BKT > kbw && k0 < kew) {   // wave-uniform
             const T* as = As + cur * SA::LDS_ELEMS;

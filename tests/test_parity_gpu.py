@@ -4,7 +4,7 @@
 
 Stated fp64 tolerances: with sigma_n = 0.1 NLML rtol 1e-10, gradient rtol 1e-8 on |g|_inf,
 mean atol 1e-10, variance atol 1e-11; default hp (sigma_n = 1e-4, cond(K) ~ 1e9): NLML 1e-8, gradient 1e-7 (SURVEY: 1e-6;
-measured 1.4e-9 at n = 512, cond(K) = 3.5e9 -- test_default_hp_gradient_error_is_stated prints it)."""
+measured 2.8e-9 at n = 512, cond(K) = 3.5e9 -- test_default_hp_gradient_error_is_stated prints it)."""
 import os
 
 import numpy as np
@@ -213,7 +213,7 @@ def test_mle_golden(golden):
     assert float(l3) == float(l2) and np.array_equal(g3, g2)
     l0, g0 = mle.loss_and_grad(g["a_hp0"].copy())                      # cond(K) ~ 1e9
     np.testing.assert_allclose(l0, g["a_loss0"], rtol=1e-8)
-    # SURVEY 8c states 1e-6 for this class; measured 1.5e-11 (n = 64) and 1.4e-9 (n = 512): test_default_hp_gradient_error_is_stated
+    # SURVEY 8c states 1e-6 for this class; measured 1.4e-10 (n = 64) and 2.8e-9 (n = 512): test_default_hp_gradient_error_is_stated
     np.testing.assert_allclose(g0, g["a_grad0"], rtol=1e-7, atol=1e-7 * np.abs(g["a_grad0"]).max())
     # cfg1 known answer
     gpb = pg.Exact_GP(T(g["b_x"]), T(g["b_y"]), se_wn())
@@ -524,7 +524,7 @@ def test_headline_size_properties():
 
 
 def test_cfg5_size_fp32_tracks_fp64():
-    """BASELINE config 5's per-expert size, n = 33792 (NBO = 2048 with the background split), Matern-5/2, D = 16: the fp32
+    """BASELINE config 5's per-expert size, n = 33792 (two levels of the recursive split, 2048-column outer panels below it), Matern-5/2, D = 16: the fp32
     NLML against the fp64 HIP path on the same data, rtol 1e-3 (sigma_n = 0.1)."""
     n, d = 33792, 16
     x, y = orc.synth(n, d, seed=55)
