@@ -211,17 +211,44 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
         if (k0 + BKT > kbw && k0 < kew) {   // wave-uniform
             const T* as = As + cur * SA::LDS_ELEMS;
             const T* bs = Bs + cur * SB::LDS_ELEMS;
+            // Fragments one k-step ahead (round 4) in the forms with an M/N-contiguous operand: its reads of consecutive k-steps lie 4
+            // LDS rows apart and do not pair into one ds_read2, so the compiler left every k-step's eight MFMAs behind that step's own
+            // three reads -- four exposed LDS latencies per K tile in TN / TT / NN against two in NT.  (NT keeps the plain loop: it is
+            // at 128 VGPRs, and the second fragment set put a scratch reload into its K loop: 70.1 -> 68.9 TFLOP/s.)
+            constexpr bool PF = TA || !TB;
+            if constexpr (PF) {
+                T a[2][MIM], bq[2][MIN];
 #pragma unroll
-            for (int kk = 0; kk < BKT / 4; ++kk) {
-                T a[MIM], bq[MIN];
+                for (int i = 0; i < MIM; ++i) a[0][i] = SA::frag(as, wm * WTM + i * 16 + fr, fk);
 #pragma unroll
-                for (int i = 0; i < MIM; ++i) a[i] = SA::frag(as, wm * WTM + i * 16 + fr, kk * 4 + fk);
+                for (int j = 0; j < MIN; ++j) bq[0][j] = SB::frag(bs, wn * WTN + j * 16 + fr, fk);
 #pragma unroll
-                for (int j = 0; j < MIN; ++j) bq[j] = SB::frag(bs, wn * WTN + j * 16 + fr, kk * 4 + fk);
+                for (int kk = 0; kk < BKT / 4; ++kk) {
+                    const int c = kk & 1, nx = c ^ 1;
+                    if (kk + 1 < BKT / 4) {
 #pragma unroll
-                for (int i = 0; i < MIM; ++i)
+                        for (int i = 0; i < MIM; ++i) a[nx][i] = SA::frag(as, wm * WTM + i * 16 + fr, (kk + 1) * 4 + fk);
 #pragma unroll
-                    for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
+                        for (int j = 0; j < MIN; ++j) bq[nx][j] = SB::frag(bs, wn * WTN + j * 16 + fr, (kk + 1) * 4 + fk);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MIM; ++i)
+#pragma unroll
+                        for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(a[c][i], bq[c][j], acc[i][j]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BKT / 4; ++kk) {
+                    T a[MIM], bq[MIN];
+#pragma unroll
+                    for (int i = 0; i < MIM; ++i) a[i] = SA::frag(as, wm * WTM + i * 16 + fr, kk * 4 + fk);
+#pragma unroll
+                    for (int j = 0; j < MIN; ++j) bq[j] = SB::frag(bs, wn * WTN + j * 16 + fr, kk * 4 + fk);
+#pragma unroll
+                    for (int i = 0; i < MIM; ++i)
+#pragma unroll
+                        for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(a[i], bq[j], acc[i][j]);
+                }
             }
         }
         if (kt + 1 < nk) {
