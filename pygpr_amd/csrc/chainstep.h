@@ -41,8 +41,16 @@ __device__ __forceinline__ bool cs_spin_ge(int* flag, int want, const CsWait& w)
         __builtin_amdgcn_s_sleep(2);
     }
 }
+// Experts together on the coupled chain (round 4): the kernels take a second grid dimension, one expert each, with its own matrix,
+// diagonal-block inverses, flag words (they live in each expert's work buffer) and status word.
+struct CsBatch {
+    int nexp;
+    long eA, eInv;    // strides of the matrices and of the inverse blocks (elements)
+    long eF;          // stride of the flag arrays (ints)
+};
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, const CsWait& wt, int* info, int* early_k = nullptr, int* browe_k = nullptr, int allow_tlog = 1);   // early_k: two-phase hand-over
-int pg_flagset(hipStream_t st, int* flag, int value);
+               int* diag_next, const CsWait& wt, int* info, int* early_k = nullptr, int* browe_k = nullptr, int allow_tlog = 1,
+               const CsBatch* cb = nullptr);   // early_k: two-phase hand-over
+int pg_flagset(hipStream_t st, int* flag, int value, int nexp = 1, long eF = 0);
 int pg_spin_probe_launch(hipStream_t st, int* flag, const CsWait& w, long long* out);   // tests: one bounded wait on a flag nobody sets

@@ -373,8 +373,16 @@ template <typename T>
 __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A, long lda, int o0, int k0, int has_next,
                                                                const T* __restrict__ inv, int* done_k, int* brow_k, int* diag_next,
                                                                CsWait tmo, int* info, int direct, long long* tlog, int* early_k,
-                                                               int* browe_k, int rows16) {
+                                                               int* browe_k, int rows16, CsBatch cb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (cb.nexp > 1) {      // blockIdx.y = expert
+        const long e = blockIdx.y;
+        A += e * cb.eA; inv += e * cb.eInv; info += e;
+        done_k += e * cb.eF; brow_k += e * cb.eF; diag_next += e * cb.eF; tmo.tmo += e * cb.eF;
+        if (early_k) early_k += e * cb.eF;
+        if (browe_k) browe_k += e * cb.eF;
+        tlog = nullptr;
+    }
     const int w = blockIdx.x;
     if (w < CS_NCRIT)
         cs_rows_body<T, 1>(smem_raw, A, lda, k0 + NB + 16 * w, o0, k0, has_next != 0, true, inv, done_k, brow_k, diag_next, CS_NCRIT,
@@ -387,11 +395,12 @@ __global__ __launch_bounds__(CS_NTH, 4) void pg_rowstep_kernel(T* __restrict__ A
                            diag_next, CS_NCRIT, tmo, info, direct, nullptr);
 }
 
-__global__ void pg_flagset_kernel(int* flag, int value) { __hip_atomic_store(flag, value, RLX_AGENT); }
+__global__ void pg_flagset_kernel(int* flag, int value, long eF) { __hip_atomic_store(flag + blockIdx.x * eF, value, RLX_AGENT); }
 
 template <typename T>
 int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_next, const T* inv, int* done_k, int* brow_k,
-               int* diag_next, const CsWait& tmo, int* info, int* early_k, int* browe_k, int allow_tlog) {
+               int* diag_next, const CsWait& tmo, int* info, int* early_k, int* browe_k, int allow_tlog, const CsBatch* cbp) {
+    const CsBatch cb = cbp ? *cbp : CsBatch{1, 0, 0, 0};
     const int m = n - k0 - NB;
     if (m <= 0 || m % NB) { pg_set_error("pg_rowstep: %d rows below the tile", m); return -2; }
     const size_t lds = (size_t)(32 * CS_XLD + 32 * CS_CLD + NB * CS_CLD) * sizeof(T);
@@ -405,20 +414,20 @@ int pg_rowstep(hipStream_t st, T* A, long lda, int n, int o0, int k0, int has_ne
     static const int rows16_env = getenv("PG_CS_ROWS16") ? atoi(getenv("PG_CS_ROWS16")) : 4096;   // rows at or below which every workgroup takes 16 rows
     static const int rows16_direct = getenv("PG_CS_ROWS16_DIRECT") ? atoi(getenv("PG_CS_ROWS16_DIRECT")) : 1;
     const int rows16 = (rows16_env > 0 && m <= rows16_env) ? (rows16_direct ? 2 : 1) : 0;
-    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / (rows16 ? 16 : 32)), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
+    hipLaunchKernelGGL(pg_rowstep_kernel<T>, dim3(8 + (m - NB) / (rows16 ? 16 : 32), cb.nexp), dim3(CS_NTH), lds, st, A, lda, o0, k0, has_next, inv, done_k,
                        brow_k, diag_next, tmo, info, direct,
                        // (the in-kernel time log lives behind the flag words of a factorisation's work buffer: never for a caller that
                        //  brings its own small flag array, pg_rowstep_raw)
                        (allow_tlog && getenv("PG_CS_TLOG")) ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (k0 / NB) : nullptr, direct ? early_k : nullptr,
-                       browe_k, rows16);
+                       browe_k, rows16, cb);
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*, int*, int*, int);
-template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*, int*, int*, int);
+template int pg_rowstep<double>(hipStream_t, double*, long, int, int, int, int, const double*, int*, int*, int*, const CsWait&, int*, int*, int*, int, const CsBatch*);
+template int pg_rowstep<float>(hipStream_t, float*, long, int, int, int, int, const float*, int*, int*, int*, const CsWait&, int*, int*, int*, int, const CsBatch*);
 
-int pg_flagset(hipStream_t st, int* flag, int value) {
-    hipLaunchKernelGGL(pg_flagset_kernel, dim3(1), dim3(1), 0, st, flag, value);
+int pg_flagset(hipStream_t st, int* flag, int value, int nexp, long eF) {
+    hipLaunchKernelGGL(pg_flagset_kernel, dim3(nexp), dim3(1), 0, st, flag, value, eF);
     PG_CHECK(hipGetLastError());
     return 0;
 }

@@ -8,7 +8,8 @@ template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long l
                                   long eA = 0, long eInv = 0);
 // The same leaf as one half of the flag-coupled chain (chainstep.hip): waits for *ready >= want, factors, sets *done.
 struct CsWait;
+struct CsBatch;
 // *early (nullable): raised by the third form once the first four block rows (64 rows) of the tile's inverse are in memory.
 bool pg_leaf_has_early();
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
-                                       const CsWait& tmo, int* early = nullptr);
+                                       const CsWait& tmo, int* early = nullptr, const CsBatch* cb = nullptr);   // cb: one workgroup per expert

@@ -1144,8 +1144,15 @@ __global__ __launch_bounds__(NTH) void pg_leaf2s_kernel(T* __restrict__ A, long 
 template <typename T, bool WT, bool BLK = false>
 __global__ __launch_bounds__(NTH) void pg_leaf3s_kernel(T* __restrict__ A, long lda, T* __restrict__ inv, int* __restrict__ info,
                                                         int col0, int* ready, int want, int* done, CsWait tmo, long long* tlog, int nf3,
-                                                        int* early) {
+                                                        int* early, CsBatch cb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (cb.nexp > 1) {      // experts together: blockIdx.x = expert
+        const long e = blockIdx.x;
+        A += e * cb.eA; inv += e * cb.eInv; info += e;
+        ready += e * cb.eF; done += e * cb.eF; tmo.tmo += e * cb.eF;
+        if (early) early += e * cb.eF;
+        tlog = nullptr;
+    }
     if (tlog && threadIdx.x == 0) tlog[0] = wall_clock64();
     if (threadIdx.x == 0) {
         if (!cs_spin_ge(ready, want, tmo)) atomicCAS(info, 0, -1);
@@ -1186,7 +1193,8 @@ bool pg_leaf_has_early() {   // the coupled leaf raises its early flag before it
     return v;
 }
 template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, int* info, int col0, int* ready, int want, int* done,
-                                       const CsWait& tmo, int* early) {
+                                       const CsWait& tmo, int* early, const CsBatch* cbp) {
+    const CsBatch cb = cbp ? *cbp : CsBatch{1, 0, 0, 0};
     const size_t lds = (size_t)(NB * LD + 8 * 16 * DLD + 2 + 16 + F3_STAGE) * sizeof(T) + 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1222,13 +1230,14 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
                                ((getenv("PG_LEAF3_DIAG") && atoi(getenv("PG_LEAF3_DIAG"))) ? 64 : 0);
         // blocked diagonal factor (leaf3_factor_blk: fp64, default; PG_LEAF3_BLK=0: the row-per-lane factor) -- a kernel of its own per form
         if (pg_leaf3_blk() && sizeof(T) == 8) {
-            if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
-            else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
-        } else if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
-        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early);
+            if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true, true>), dim3(cb.nexp), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early, cb);
+            else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false, true>), dim3(cb.nexp), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early, cb);
+        } else if (wt) hipLaunchKernelGGL((pg_leaf3s_kernel<T, true>), dim3(cb.nexp), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early, cb);
+        else hipLaunchKernelGGL((pg_leaf3s_kernel<T, false>), dim3(cb.nexp), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo, tl, nf3, early, cb);
         PG_CHECK(hipGetLastError());
         return 0;
     }
+    if (cb.nexp > 1) { pg_set_error("pg_leaf_sync: the second leaf form (PG_LEAF3=0) does not batch experts"); return -2; }
     if (wt) hipLaunchKernelGGL((pg_leaf2s_kernel<T, true>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
                                getenv("PG_CS_TLOG") ? reinterpret_cast<long long*>(tmo.tmo) + 512 + 48 * (col0 / NB) : nullptr, abl);
     else hipLaunchKernelGGL((pg_leaf2s_kernel<T, false>), dim3(1), dim3(NTH), lds, st, A, lda, inv, info, col0, ready, want, done, tmo,
@@ -1236,8 +1245,8 @@ template <typename T> int pg_leaf_sync(hipStream_t st, T* A, long lda, T* inv, i
     PG_CHECK(hipGetLastError());
     return 0;
 }
-template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&, int*);
-template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&, int*);
+template int pg_leaf_sync<double>(hipStream_t, double*, long, double*, int*, int, int*, int, int*, const CsWait&, int*, const CsBatch*);
+template int pg_leaf_sync<float>(hipStream_t, float*, long, float*, int*, int, int*, int, int*, const CsWait&, int*, const CsBatch*);
 
 template <typename T> int pg_leaf(hipStream_t st, T* A, long lda, T* inv, long ldi, int* info, int col0, int ablate, int nexp, long eA,
                                   long eInv) {

@@ -15,7 +15,8 @@ template <typename T> struct BuildReq {
 };
 // Batched experts: nexp independent problems of the same size in every launch of the call (A + e * eA, the workspace + e * eInv,
 // Minv + e * eM, info[e]; a folded build reads X + e * eX and hp + e * ehp).  The per-step launches of the latency-bound chain are
-// then paid once per batch instead of once per expert; the schedule is the classic chain (no flag-coupled kernels).
+// then paid once per batch instead of once per expert; batches that are still latency-bound (experts of >= 2048 points, <= 24576 rows in
+// all) take the flag-coupled chain with an expert dimension (round 4), the others the classic chain.
 struct ExpBatch {
     int nexp;
     long eA, eInv, eM, eX, ehp;

@@ -603,7 +603,16 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     static const int sync_env = getenv("PG_SYNC_ROWS") ? atoi(getenv("PG_SYNC_ROWS")) : -1;
     const int sync_rows = sync_env >= 0 ? sync_env : ((Minv && ctx->bg && n > 8192) ? 0 : 8192);
     hipStream_t rows_stream = ctx->rows;      // the handle's own (capi.hip)
-    const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0 && nexp == 1;
+    // Experts together take the coupled chain too (round 4) -- one leaf workgroup and one grid row of rows workgroups per expert, flag
+    // words in each expert's own work buffer -- where the batch is still latency-bound: experts of at least 2048 points and at most
+    // 24576 rows in all.  Measured (fit = build + factor + inverse + alpha, D = 16, coupled against classic, same box): 2 x 4096 3.18 / 3.83 ms,
+    // 4 x 4096 5.21 / 5.47, 8 x 2048 2.05 / 2.35, 8 x 3072 4.85 / 5.00; beyond that the batch's skinny products fill the chip either way and
+    // the resident kernels only take slots from the trailing updates (8 x 4096 9.32 / 9.06, 8 x 9216 78.7 / 75.5; 16 x 2048 and 3 x 8192
+    // equal), and below 2048 points three panels are too few (8 x 1024 0.79 / 0.73).  PG_CS_BATCHED=0: never; 2: whenever it can run.
+    static const int cs_batched = getenv("PG_CS_BATCHED") ? atoi(getenv("PG_CS_BATCHED")) : 1;
+    const bool batch_cp = cs_batched && nexp <= 24 && pg_leaf_has_early() && (cs_batched == 2 || (n >= 2048 && (long)nexp * n <= 24576));
+    const bool want_cp = ctx->lookahead && !ctx->prof_on && ctx->coupled && rows_stream && sync_rows > 0 && ctx->panel_mode == 0 &&
+                         (nexp == 1 || batch_cp);
     std::vector<int> pb;      // panel o = columns [pb[o], pb[o+1])
     static const int cs_panel = getenv("PG_CS_PANEL") ? atoi(getenv("PG_CS_PANEL")) : 384;   // round 3, same box: 512 -> 384: n = 4096 1.64 -> 1.60 ms, 8192 5.10 -> 5.03, 16384 equal
     // experiment: wider coupled panels while the trailing update still bounds the step (deeper K for Sb), narrow ones in the chain-bound tail
@@ -669,11 +678,13 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     // classic chain by a crude model (62 us per 128 columns + n^3 / 3 flop at 35 TFLOP/s), at least 50 ms -- a leaf's wait may cover a
     // whole trailing update of the part before the coupled region (3 ms at n = 16384), never a multiple of the call
     const CsWait cw = {f_tmo, ctx->tmo_dev, pg_wait_ticks(ctx, n), ctx->chain_epoch};
+    const CsBatch cbat = {nexp, eA, eI, (long)(eI * (long)sizeof(T) / (long)sizeof(int))};   // flag stride in ints
     // two-phase hand-over (chainstep.hip): only the third leaf form raises the early flag
     static const bool two_phase_env = !(getenv("PG_CS_TWO_PHASE") && atoi(getenv("PG_CS_TWO_PHASE")) == 0);
     const bool two_phase = two_phase_env && pg_leaf_has_early();
     if (o_s < npan) {
-        PG_CHECK(hipMemsetAsync(f_diag, 0, (size_t)((5 * nblk + 1 + 3) / 4) * 16, ps));   // ps: behind the fork event
+        // (ps: behind the fork event; experts together: the same words in every expert's work buffer)
+        PG_CHECK(hipMemset2DAsync(f_diag, (size_t)(nexp > 1 ? eI : pg_potrf_worksize_impl(n)) * sizeof(T), 0, (size_t)((5 * nblk + 1 + 3) / 4) * 16, (size_t)nexp, ps));
     }
     // Coupled panels while the trailing update still bounds the step (more than `sa_rows` rows right of the panel): the next panel's
     // columns take this panel's update as ONE product on the update stream ("Sa", then a flag for the next leaf) instead of through the
@@ -691,7 +702,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             hipStream_t rs = rows_stream;
             if (o == o_s) {
                 // everything so far that touched these columns ran on the panel stream or was waited for there
-                if ((rc = pg_flagset(ps, f_diag + o0 / NB, PG_CS_NCRIT))) return rc;
+                if ((rc = pg_flagset(ps, f_diag + o0 / NB, PG_CS_NCRIT, nexp, cbat.eF))) return rc;
                 if ((rc = pool_event(ctx, 4 + 2 * npan, &ev))) return rc;
                 PG_CHECK(hipEventRecord(ev, ps));
                 PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
@@ -700,7 +711,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                 const int kb = k0 / NB;
                 T* inv = invD + (long)kb * NB * NB;
                 if ((rc = pg_leaf_sync<T>(ps, A + (long)k0 * lda + k0, lda, inv, info, k0 + col_off, f_diag + kb, PG_CS_NCRIT, f_done + kb, cw,
-                                          two_phase ? f_early + kb : nullptr)))
+                                          two_phase ? f_early + kb : nullptr, &cbat)))
                     return rc;
                 if (n - k0 - NB <= 0) break;
                 const int c = k0 + NB;                       // the block column this step brings up to date
@@ -722,7 +733,7 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
                 }
                 if ((rc = pg_rowstep<T>(rs, A, lda, n, wstart, k0, last_sa ? 0 : 1, inv, f_done + kb, f_brow + kb, f_diag + kb + 1, cw, info,
-                                        (two_phase && !last_sa) ? f_early + kb : nullptr, f_browe + kb)))
+                                        (two_phase && !last_sa) ? f_early + kb : nullptr, f_browe + kb, 1, &cbat)))
                     return rc;
             }
         }
@@ -841,7 +852,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.M = n - o2; p.N = o3 - o2; p.K = oend - o0;
             p.A = A + (long)o2 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o2 * lda + o2; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1;
-            const long tiles = (long)(p.M / 128) * (p.N / 128);
+            batched(p, eA, eA, eA);
+            const long tiles = (long)(p.M / 128) * (p.N / 128) * nexp;
             if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
             if ((rc = pool_event(ctx, 9 + 3 * npan + o, &ev))) return rc;   // ev_near[o]
             PG_CHECK(hipEventRecord(ev, us));
@@ -850,7 +862,8 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
             p.M = p.N = n - o3; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
             p.C = A + (long)o3 * lda + o3; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
-            const long ftiles = (long)(p.M / 128) * (p.M / 128 + 1) / 2;
+            batched(p, eA, eA, eA);
+            const long ftiles = (long)(p.M / 128) * (p.M / 128 + 1) / 2 * nexp;
             static const long sb_thresh2 = getenv("PG_SB_TILE_THRESH") ? atol(getenv("PG_SB_TILE_THRESH")) : 2048;
             if ((rc = pg_gemm<T>(ctx, us, ftiles < sb_thresh2 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         } else if (m2 > 0) {  // Sb(o)

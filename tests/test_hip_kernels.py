@@ -1040,6 +1040,33 @@ def test_build_potrf_trtri_checked_falls_back_inside_the_call(ops, forced_timeou
 
 
 @pytest.mark.gpu
+def test_batched_coupled_chain_timeout_falls_back(ops, forced_timeout):
+    """Experts together on the coupled chain (3 x 2304 points) with every wait forced to expire: every expert reports info = -1, the
+    handle switches itself to the classic chain, and the repeated call gives LAPACK's factors -- what Exact_GP.update / MLE do at their
+    one synchronisation point (gpr._checked)."""
+    nexp, n, d = 3, 2304, 3
+    covs = [orc.SE, orc.WN]
+    rng = np.random.default_rng(77)
+    x = rng.random((nexp, n, d))
+    hp = np.tile(np.array([1.0, 0.9, 1.1, 0.8, 0.2]), (nexp, 1))
+    spec = _spec(covs, d)
+    a = ops.empty(nexp, n, n)
+    invd = ops.empty(nexp, ops.potrf_worksize(n, torch.float64))
+    info = torch.zeros(nexp, dtype=torch.int32, device="cuda")
+    before = ops.chain_timeouts()
+    ops.build_factor_batched(spec, dev(hp), dev(x), n * d, a, invd, info, None, jitter=1e-7)
+    assert ops.last_coupled_panels() == coupled_count(n)
+    torch.cuda.synchronize()
+    assert info.tolist() == [-1] * nexp
+    assert ops.chain_timeouts() == before + 1 and ops.coupled_chain() == 0
+    ops.build_factor_batched(spec, dev(hp), dev(x), n * d, a, invd, info, None, jitter=1e-7)
+    assert info.tolist() == [0] * nexp and ops.last_coupled_panels() == 0
+    for e in range(nexp):
+        k = orc.kernel(covs, hp[e], x[e], form="direct") + 1e-7 * np.eye(n)
+        np.testing.assert_allclose(np.tril(host(a[e])), np.linalg.cholesky(k), atol=1e-11)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nexp,n,d,shared_x", [(4, 1500, 8, False), (10, 100, 3, False), (3, 700, 16, True)])
 def test_batched_gradient_path_matches_the_single_expert_calls(ops, nexp, n, d, shared_x):
     """Round 4: pg_alpha_nlml_batched / pg_lauum_batched / pg_nlml_grad_batched after pg_build_potrf_trtri_batched -- the gradient
@@ -1174,10 +1201,11 @@ def test_wait_budget_is_scaled_to_the_call(ops):
 
 # ---- batched experts: one call, every launch covers all of them (PyGPR/gpr.py:65-74 factorises a batch in one tc.cholesky) ------
 @pytest.mark.gpu
-@pytest.mark.parametrize("nexp,n,with_inv", [(8, 4096, True), (3, 1000, False), (10, 100, True)])
+@pytest.mark.parametrize("nexp,n,with_inv", [(8, 4096, True), (3, 1000, False), (10, 100, True), (3, 2500, True), (5, 4000, False)])
 def test_batched_factorisation(ops, nexp, n, with_inv):
     """pg_build_potrf_trtri_batched against LAPACK per expert (factor 1e-11, inverse 1e-9), and bit for bit against the
-    single-expert call on the classic chain (the batch only widens the grids); expert 1 gets different hyper-parameters, and a
+    single-expert call on the same chain -- classic, or coupled where the batch takes it (the batch only widens the grids);
+    expert 1 gets different hyper-parameters, and a
     NaN in ONE expert's points fails that expert alone (info[e] > 0, the others' factors untouched)."""
     from pygpr_amd._ops import pad_to
 
@@ -1195,7 +1223,11 @@ def test_batched_factorisation(ops, nexp, n, with_inv):
     info = torch.ones(nexp, dtype=torch.int32, device="cuda")
     minv = ops.zeros(nexp, npad, npad) if with_inv else None
     ops.build_factor_batched(spec, hpd, xd, xd.stride(0), a, invd, info, minv, jitter=1e-7)
-    assert info.tolist() == [0] * nexp and ops.last_coupled_panels() == 0
+    # round 4: a batch that is still latency-bound (experts of >= 2048 points, <= 24576 rows in all: the 3 x 2500 and 5 x 4000 cases)
+    # takes the coupled chain -- one leaf workgroup and one grid row of rows workgroups per expert
+    import os
+    want_coupled = coupled_count(npad) if (npad >= 2048 and nexp * npad <= 24576 and os.environ.get("PG_CS_BATCHED", "1") == "1") else 0
+    assert info.tolist() == [0] * nexp and ops.last_coupled_panels() == want_coupled
     la, lm = host(a), (host(minv) if with_inv else None)
     for e in sorted({0, 1, nexp - 1}):
         k = orc.kernel(covs, hp[e], x[e], form="direct") + 1e-7 * np.eye(n)
@@ -1203,8 +1235,9 @@ def test_batched_factorisation(ops, nexp, n, with_inv):
         np.testing.assert_allclose(np.tril(la[e])[:n, :n], chol, atol=1e-11)
         if with_inv:
             np.testing.assert_allclose(np.tril(lm[e])[:n, :n], np.linalg.inv(chol), atol=1e-9)
-    # the same expert alone, classic chain: identical bits
-    ops.set_coupled_chain(0)
+    # the same expert alone on the same chain (coupled when the batch was): identical bits
+    if not want_coupled:
+        ops.set_coupled_chain(0)
     try:
         for e in (1, nexp - 1):
             a1 = ops.empty(npad, npad)
