@@ -128,7 +128,7 @@ static int gemm_raw_t(pg_handle h, int variant, int M, int N, int K, double alph
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
     p.alpha = (T)alpha; p.beta = (T)beta;
-    p.tri = tri; p.klo = klo; p.khi = khi;
+    p.tri = tri; p.klo = klo & 3; p.khi = khi; p.krev = (klo >> 2) & 1;   // (klo bit 2: reverse walk, measurement only)
     p.sA = p.sB = p.sC = 0; p.batch = 1;
     p.nexp = 1; p.eA = p.eB = p.eC = 0; p.einfo = 0;
     p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;

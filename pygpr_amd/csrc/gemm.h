@@ -16,6 +16,7 @@ template <typename T> struct GemmP {
     T alpha, beta;
     int tri;          // 1: only tiles on or below the diagonal (BM == BN)
     int klo, khi;     // K-range from a triangular operand: 0 none, 1 follows the tile row, 2 the tile column
+    int krev;         // klo launches: walk each tile's K range from its end downwards (all tiles start at the same k)
     long sA, sB, sC;  // batch strides (elements), grid.y = batch * nexp
     int batch;
     int nexp;         // independent problems of the same shape in one launch (batched experts): z = blockIdx.y -> (z % batch, z / batch)

@@ -116,6 +116,10 @@ __device__ __forceinline__ void gemm_decode(const GemmP<T>& p, int wg, int& ti, 
         while ((long)ti * (ti + 1) / 2 > wg) --ti;
         while ((long)(ti + 1) * (ti + 2) / 2 <= wg) ++ti;
         tj = wg - ti * (ti + 1) / 2;
+        // Workgroup b runs on XCD b mod 8.  Rotating the row's columns by its first index mod 8 gives that XCD the tile COLUMNS congruent
+        // to it (up to the wrap at the row's end): of the column panels a row reads, each L2 holds an eighth instead of all of them
+        // (round 4; with the reverse K walk of p.krev the tiles in flight are in step on those panels).
+        if (p.krev & 1) tj = (tj + (int)(((long)ti * (ti + 1) / 2) & 7)) % (ti + 1);
     } else if (grouped) {
         const int tn = p.N / BN, tmr = p.M / BM;
         const int band = wg / (GR * tn), r0 = band * GR;
@@ -192,9 +196,15 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
     sa.init(p.lda, tid);
     sb.init(p.ldb, tid);
     const int nk = (kend - kbeg) / BKT;
+    // K ranges that START with the tile row / column (klo: L^-T L^-1, the triangular inverse's first products) are walked from the END
+    // downwards when the launch asks for it (p.krev): every tile then starts at the same k, and the tiles in flight together -- launched
+    // longest first, so of similar length -- stay in step on the row slabs they share through L2 instead of running a fixed 128 (i' - i)
+    // rows apart for their whole life.  Only the order of an element's k tiles changes (results agree to rounding).
+    const bool rev = p.klo != 0 && p.krev != 0;
+    const int kfirst = rev ? kend - BKT : kbeg, kstep = rev ? -BKT : BKT;
     if (nk > 0) {
-        sa.load(SA::origin(A, p.lda, m0, kbeg));
-        sb.load(SB::origin(B, p.ldb, n0, kbeg));
+        sa.load(SA::origin(A, p.lda, m0, kfirst));
+        sb.load(SB::origin(B, p.ldb, n0, kfirst));
         sa.store(As, tid);
         sb.store(Bs, tid);
     }
@@ -203,10 +213,10 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const int k0 = kbeg + kt * BKT;
+        const int k0 = kfirst + kt * kstep;
         if (kt + 1 < nk) {
-            sa.load(SA::origin(A, p.lda, m0, k0 + BKT));
-            sb.load(SB::origin(B, p.ldb, n0, k0 + BKT));
+            sa.load(SA::origin(A, p.lda, m0, k0 + kstep));
+            sb.load(SB::origin(B, p.ldb, n0, k0 + kstep));
         }
         if (k0 + BKT > kbw && k0 < kew) {   // wave-uniform
             const T* as = As + cur * SA::LDS_ELEMS;

@@ -377,7 +377,7 @@ template <typename T> static GemmP<T> gp0() {
     p.lda = p.ldb = p.ldc = 0;
     p.M = p.N = p.K = 0;
     p.alpha = (T)1; p.beta = (T)0;
-    p.tri = p.klo = p.khi = 0;
+    p.tri = p.klo = p.khi = 0; p.krev = 0;
     p.sA = p.sB = p.sC = 0; p.batch = 1;
     p.nexp = 1; p.eA = p.eB = p.eC = 0; p.einfo = 0;
     p.part = nullptr; p.ldp = 0; p.info = nullptr; p.noxcd = 0;
@@ -1000,6 +1000,8 @@ int pg_lauum_t(pg_ctx* ctx, hipStream_t st, int n, const T* M, long ldm, T* Kinv
     GemmP<T> p = gp0<T>();
     p.M = p.N = p.K = n; p.A = M; p.lda = ldm; p.B = M; p.ldb = ldm; p.C = Kinv; p.ldc = ldk;
     p.tri = 1; p.klo = 1;
+    static const int krev_env = getenv("PG_LAUUM_KREV") ? atoi(getenv("PG_LAUUM_KREV")) : 1;
+    p.krev = krev_env;
     if (eb) { p.nexp = eb->nexp; p.eA = p.eB = eb->eM; p.eC = eb->eA; }      // experts together: Minv + e eM -> Kinv + e eA
     return pg_gemm<T>(ctx, st, GEMM_TN_128, p);
 }

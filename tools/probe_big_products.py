@@ -31,10 +31,12 @@ for pad in pads:
     res.append(("panel L21 = K21 M11^T (NT khi=2)", fl_tri_k, ev(lambda: raw(GEMM_NT, h, h, h, 1.0, m + off(h, 0), ld, m, ld, 0.0, a + off(h, 0), ld, 0, 0, 2))))
     res.append(("update A22 -= L21 L21^T (NT tri)", 2.0 * 128 * 128 * h * tri_tiles, ev(lambda: raw(GEMM_NT, h, h, h, -1.0, a + off(h, 0), ld, a + off(h, 0), ld, 1.0, a + off(h, h), ld, 1, 0, 0))))
     res.append(("S = (L21 M11)^T (TT klo=1)", fl_tri_k, ev(lambda: raw(GEMM_TT, h, h, h, 1.0, m, ld, a + off(h, 0), ld, 0.0, m + off(0, h), ld, 0, 1, 0))))
+    res.append(("S, K walked from its end (klo=1, krev)", fl_tri_k, ev(lambda: raw(GEMM_TT, h, h, h, 1.0, m, ld, a + off(h, 0), ld, 0.0, m + off(0, h), ld, 0, 5, 0))))
     res.append(("M21 = -M22 S^T (NT khi=1)", fl_tri_k, ev(lambda: raw(GEMM_NT, h, h, h, -1.0, m + off(h, h), ld, m + off(0, h), ld, 0.0, m + off(h, 0), ld, 0, 0, 1))))
     T = N // 128
     fl_lauum = 2.0 * 128 * 128 * 128 * sum((T - i) * (i + 1) for i in range(T))
     res.append(("K^-1 = M^T M (TN tri klo=1, n = 16384)", fl_lauum, ev(lambda: raw(GEMM_TN, N, N, N, 1.0, m, ld, m, ld, 0.0, a, ld, 1, 1, 0))))
+    res.append(("K^-1, K walked from its end + columns dealt to XCDs (krev)", fl_lauum, ev(lambda: raw(GEMM_TN, N, N, N, 1.0, m, ld, m, ld, 0.0, a, ld, 1, 5, 0))))
     print(f"ld = {ld}:", flush=True)
     for name, fl, ms in res:
         print(f"   {name:44s} {ms:7.3f} ms  {fl / ms / 1e9:5.1f} TFLOP/s", flush=True)
