@@ -1044,6 +1044,9 @@ def test_batched_coupled_chain_timeout_falls_back(ops, forced_timeout):
     """Experts together on the coupled chain (3 x 2304 points) with every wait forced to expire: every expert reports info = -1, the
     handle switches itself to the classic chain, and the repeated call gives LAPACK's factors -- what Exact_GP.update / MLE do at their
     one synchronisation point (gpr._checked)."""
+    import os
+    if os.environ.get("PG_CS_BATCHED") == "0":
+        pytest.skip("the batch stays on the classic chain with PG_CS_BATCHED=0")
     nexp, n, d = 3, 2304, 3
     covs = [orc.SE, orc.WN]
     rng = np.random.default_rng(77)
@@ -1226,7 +1229,9 @@ def test_batched_factorisation(ops, nexp, n, with_inv):
     # round 4: a batch that is still latency-bound (experts of >= 2048 points, <= 24576 rows in all: the 3 x 2500 and 5 x 4000 cases)
     # takes the coupled chain -- one leaf workgroup and one grid row of rows workgroups per expert
     import os
-    want_coupled = coupled_count(npad) if (npad >= 2048 and nexp * npad <= 24576 and os.environ.get("PG_CS_BATCHED", "1") == "1") else 0
+    mode = os.environ.get("PG_CS_BATCHED", "1")          # 0: never, 1: the rule below, 2: whenever the look-ahead has three panels
+    rule = (npad >= 2048 and nexp * npad <= 24576) if mode == "1" else (mode == "2" and npad >= 1024 and nexp <= 24)
+    want_coupled = coupled_count(npad) if rule else 0
     assert info.tolist() == [0] * nexp and ops.last_coupled_panels() == want_coupled
     la, lm = host(a), (host(minv) if with_inv else None)
     for e in sorted({0, 1, nexp - 1}):
