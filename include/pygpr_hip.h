@@ -281,7 +281,8 @@ int pg_coupled_chain(pg_handle h);
  * 53 ms, 8192: 0.18 s, 16384: 1.0 s); > 0: that many microseconds per wait; < 0: every wait expires at once -- the deterministic test
  * hook of the fall-back path.  pg_chain_timeouts: how many expiries this handle has seen.  Each one switches the handle to the classic
  * chain, TEMPORARILY: after pg_set_rearm_after(h, calls) further factorisations (default 8; PG_CS_REARM; 0 = never) the handle probes
- * its queues again and takes the coupled chain back by itself (pg_chain_rearms counts); pg_set_coupled_chain(h, 1) does so at once,
+ * its queues again and takes the coupled chain back by itself (pg_chain_rearms counts; a time-out that follows a re-arm doubles that
+ * distance, up to 4096, so that a GPU shared for good with another process costs one wait budget ever more rarely); pg_set_coupled_chain(h, 1) does so at once,
  * pg_set_coupled_chain(h, -1) switches to the classic chain as a time-out would (stream kept, automatic re-arm applies),
  * pg_set_coupled_chain(h, 0) for good (rows stream released). */
 int pg_set_spin_budget(pg_handle h, long microseconds);

@@ -73,7 +73,10 @@ static void poll_timeout(pg_ctx* h) {
         const int v = *(volatile int*)h->tmo_host;     // epoch of the factorisation whose wait expired (chainstep.h)
         if (v) {
             *(volatile int*)h->tmo_host = 0;
-            if (h->coupled) { h->tmo_off = 1; h->calls_since_tmo = 0; }
+            if (h->coupled) {
+                h->tmo_off = 1; h->calls_since_tmo = 0;
+                if (h->rearms > h->rearms_seen) { h->rearm_cur = std::min(4096, std::max(1, h->rearm_cur) * 2); h->rearms_seen = h->rearms; }   // timed out again after a re-arm: back off
+            }
             h->coupled = 0;
             if (v != h->counted_epoch) {               // one count per call, however many waits expired and whenever we looked
                 h->counted_epoch = v;
@@ -186,7 +189,8 @@ static int probe_concurrent_queues(pg_ctx* c) {
 // process's resident kernels on the same GPU) is transient, the downgrade should be too.
 static void maybe_rearm(pg_ctx* h) {
     if (!h || !h->tmo_off || h->coupled || h->rearm_after <= 0) return;
-    if (++h->calls_since_tmo <= h->rearm_after) return;
+    if (h->rearm_cur < h->rearm_after) h->rearm_cur = h->rearm_after;
+    if (++h->calls_since_tmo <= h->rearm_cur) return;
     h->calls_since_tmo = 0;
     if (h->rows && h->spin_ticks >= 0 && probe_concurrent_queues(h)) {
         h->coupled = 1;
@@ -309,6 +313,7 @@ int pg_create(pg_handle* h) {
         c->timeouts = 0;
         const char* ra = getenv("PG_CS_REARM");
         c->rearm_after = ra ? std::max(0, atoi(ra)) : 8;
+        c->rearm_cur = c->rearm_after;
     }
     for (int i = 0; i < 8; ++i) PG_CHECK(hipEventCreate(&c->ev[i]));
     {
@@ -749,6 +754,7 @@ int pg_set_coupled_chain(pg_handle h, int on) {
         return 0;
     }
     h->tmo_off = 0;
+    h->rearm_cur = h->rearm_after;
     if (!on) {
         // off also RELEASES the rows stream (the handle then owns two streams)
         if (h->rows) {
@@ -792,6 +798,7 @@ int pg_set_rearm_after(pg_handle h, int calls) {
     NEED(h, "null handle");
     NEED(calls >= 0, "calls must be >= 0 (0: never re-arm automatically)");
     h->rearm_after = calls;
+    h->rearm_cur = calls;
     return 0;
 }
 int pg_chain_rearms(pg_handle h) { return h ? h->rearms : -1; }

@@ -40,6 +40,9 @@ struct pg_ctx {
     int calls_since_tmo;      // factorisations enqueued on the classic chain since then
     int rearm_after;          // ... after this many of them the handle probes again and re-arms (pg_set_rearm_after / PG_CS_REARM; 0: never)
     int rearms;               // automatic re-arms so far
+    int rearms_seen;          // re-arms already answered by a back-off
+    int rearm_cur;            // the current distance: doubled (up to 4096) by every time-out that follows a re-arm, so that a GPU shared for
+                              // good with another process' resident kernels costs one wait budget ever more rarely, not every rearm_after calls
     int chain_epoch;          // counts the factorisations that took the coupled chain; an expiry reports its call's number
     int counted_epoch;        // the last epoch whose time-out was counted
     int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory

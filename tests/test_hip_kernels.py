@@ -1167,12 +1167,25 @@ def test_a_timeout_is_temporary_the_handle_rearms_itself(ops):
         ad, _, info, coupled = _potrf_on_compute_stream(ops, a)      # the K+1-th call re-arms before it factorises
         assert info == 0 and coupled == coupled_count(n) and ops.coupled_chain() == 1 and ops.chain_rearms() == rearms + 1
         np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
+        # a time-out that FOLLOWS a re-arm doubles the distance (a GPU shared for good with another process' resident kernels must not
+        # cost a wait budget every K calls): six classic calls now, the seventh re-arms
+        ops.set_spin_budget(-1)
+        _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+        assert info == -1 and coupled == coupled_count(n)
+        ops.set_spin_budget(0)
+        assert ops.chain_timeouts() == tmos + 2 and ops.coupled_chain() == 0
+        for _ in range(6):
+            _, _, info, coupled = _potrf_on_compute_stream(ops, a)
+            assert info == 0 and coupled == 0 and ops.chain_rearms() == rearms + 1
+        ad, _, info, coupled = _potrf_on_compute_stream(ops, a)
+        assert info == 0 and coupled == coupled_count(n) and ops.chain_rearms() == rearms + 2
+        np.testing.assert_allclose(np.tril(host(ad)), chol, atol=1e-11)
         # a caller's explicit "off" is not a time-out: no automatic re-arm
         ops.set_coupled_chain(0)
         for _ in range(5):
             _, _, info, coupled = _potrf_on_compute_stream(ops, a)
             assert info == 0 and coupled == 0
-        assert ops.coupled_chain() == 0 and ops.chain_rearms() == rearms + 1
+        assert ops.coupled_chain() == 0 and ops.chain_rearms() == rearms + 2
     finally:
         ops.set_rearm_after(8)
         ops.set_spin_budget(0)
