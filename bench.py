@@ -655,6 +655,34 @@ def main():
                                  "K* build, mean and aggregation are lower order"},
             "check": check_committee(g4, xs[:mb].cpu(), hp4.numpy()),
         }
+        if legs:
+            # row f-1 at config 4's size: the FULL-covariance committee (aggregate_full_covar, gr_bcm.py:99-114) -- per expert K* build,
+            # V = L^-1 K* and K** - V^T V (n^2 m + n m^2 flop), then nc + 2 inversions of m x m matrices (m^3 each: Cholesky, L^-1,
+            # L^-T L^-1) around the weighted sum of the experts' precisions
+            mf4 = 2048
+            xf4 = xs[:mf4]
+            g4.predict(xf4, var="full")
+            torch.cuda.synchronize()
+            tf4 = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                muf4, covf4 = g4.predict(xf4, var="full")
+                torch.cuda.synchronize()
+                tf4 = min(tf4, time.perf_counter() - t0)
+            n4 = float(ng4 + nls4)
+            flopf4 = nc * (n4 ** 2 * mf4 + n4 * float(mf4) ** 2) + (float(ng4) ** 2 * mf4 + float(ng4) * float(mf4) ** 2) + (nc + 2) * float(mf4) ** 3
+            dg4 = torch.diagonal(covf4)
+            assert bool(torch.isfinite(covf4).all()) and float(dg4.min()) > 0.0
+            out["grbcm_predict_full"] = {
+                "config": "GRBCM.predict(var='full'): 8 experts x (%d global + %d local) points, D=%d, m = %d test points, one GPU" % (ng4, nls4, d4, mf4),
+                "ms": 1e3 * tf4, "points_per_s": mf4 / tf4, "cov_diag_mean": float(dg4.mean()), "cov_symmetric": bool(torch.equal(covf4, covf4.T)),
+                "roofline": {"bound": "mfma", "achieved": flopf4 / tf4 / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flopf4 / tf4 / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "algorithmic_flops": flopf4,
+                             "kernel": "pg_gemm_kernel<double,...>: V = L^-1 K* (NN, K ranges), K** - V^T V (TN, lower tiles), and the m x m inversions "
+                                       "(factor, L^-1, L^-T L^-1)",
+                             "note": "flop = nc (n^2 m + n m^2) + the global expert's share + (nc + 2) m^3"},
+            }
+            del muf4, covf4
         del g4, xs
 
     # ---- experts together (round 3): Exact_GP.update() of a batched model -- covariance build + Cholesky + L^-1 + alpha for all
