@@ -607,7 +607,7 @@ def main():
             "ms": 1e3 * tf_, "points_per_s": mf / tf_, "cov_diag_mean": float(torch.diagonal(covf).mean()), "cov_symmetric": bool(torch.equal(covf, covf.T)),
             "roofline": {"bound": "mfma", "achieved": flopf / tf_ / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flopf / tf_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "algorithmic_flops": flopf,
-                         "kernel": "pg_gemm_kernel<double, NN, 128x128> (V = L^-1 K*, K ranges) + <double, TN, 128x128> (K** - V^T V, lower tiles)",
+                         "kernel": "pg_gemm_kernel<double, NT, 128x128> (Vt = K* L^-T from the test-point-major K*, K ranges) + <double, NT> (K** - Vt Vt^T, lower tiles)",
                          "note": "flop = n^2 m (triangular product) + n m^2 (symmetric update); the K* / K** builds and the mirror are HBM-bound extras inside the time"},
         }
         del gpf, xsf, muf, covf
@@ -678,8 +678,8 @@ def main():
                 "ms": 1e3 * tf4, "points_per_s": mf4 / tf4, "cov_diag_mean": float(dg4.mean()), "cov_symmetric": bool(torch.equal(covf4, covf4.T)),
                 "roofline": {"bound": "mfma", "achieved": flopf4 / tf4 / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": flopf4 / tf4 / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "algorithmic_flops": flopf4,
-                             "kernel": "pg_gemm_kernel<double,...>: V = L^-1 K* (NN, K ranges), K** - V^T V (TN, lower tiles), and the m x m inversions "
-                                       "(factor, L^-1, L^-T L^-1)",
+                             "kernel": "pg_gemm_kernel<double,...>: Vt = K* L^-T (NT, K ranges), K** - Vt Vt^T for all experts in one launch (NT, lower tiles), and the "
+                                       "m x m inversions (factor, L^-1, L^-T L^-1: the local experts' as one batched call per step)",
                              "note": "flop = nc (n^2 m + n m^2) + the global expert's share + (nc + 2) m^3"},
             }
             del muf4, covf4

@@ -17,6 +17,7 @@ PG_MAX_COMP, PG_MAX_DIM = 4, 64
 PAD = 256  # every dimension given to the O(n^3) entry points is a multiple of this
 
 GEMM_NT, GEMM_NT_RP, GEMM_NN, GEMM_TN, GEMM_TT, GEMM_NT_64, GEMM_NT_64x128, GEMM_NT_32x64, GEMM_NT_32x128, GEMM_TT_64, GEMM_NT_32x32 = 0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11
+GEMM_TN_64 = 13
 
 
 class CovSpec(C.Structure):
@@ -58,6 +59,8 @@ _SIGS = {
     "pg_predict_mean_q_kt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _d, _vp, _vp]),
     "pg_trmm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
+    "pg_trmm_lower_kt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "pg_syrk_nt_sub_batched": (_i, [_vp, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _i, _vp]),
     "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_grbcm_weighted_prec": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _i, _vp]),

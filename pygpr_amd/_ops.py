@@ -154,6 +154,17 @@ class HipOps:
             _p(minv_all), minv_all.stride(1) if minv_all is not None else 0, minv_all.stride(0) if minv_all is not None else 0,
             nexp, self._st()), "pg_build_potrf_trtri_batched")
 
+    def potrf_trtri_batched(self, a_all, invd_all, info_all, minv_all=None):
+        """Cholesky in place (+ minv_all <- L^-1) of nexp matrices that are already in a_all [nexp, n_pad, n_pad]: the batched call
+        without a folded build (X = NULL)."""
+        self._chk(a_all, invd_all, info_all, minv_all)
+        assert info_all.dtype == torch.int32
+        nexp, n_pad = a_all.shape[0], a_all.shape[1]
+        _lib.check(self.lib.pg_build_potrf_trtri_batched(
+            self.h, _code(a_all.dtype), None, None, 0, None, 0, 0, n_pad, 0, 0.0, _p(a_all), a_all.stride(1), a_all.stride(0), n_pad,
+            _p(invd_all), invd_all.stride(0), _p(info_all), _p(minv_all), minv_all.stride(1) if minv_all is not None else 0,
+            minv_all.stride(0) if minv_all is not None else 0, nexp, self._st()), "pg_build_potrf_trtri_batched")
+
     def alpha_batched(self, minv_all, y_all, u_all, alpha_all, work_all):
         """alpha_e = minv_e^T (minv_e y_e) for all experts in three launches; y_all [nexp | 1, n_pad] (one row: shared targets),
         u_all [nexp, n_pad], work_all [nexp, (n_pad/256) n_pad]."""
@@ -300,6 +311,20 @@ class HipOps:
         _lib.check(self.lib.pg_syrk_tn_sub(self.h, _code(v.dtype), c.shape[0], v.shape[0], _p(v), v.stride(0), _p(c),
                                            c.stride(0), int(lower_only), self._st()), "pg_syrk_tn_sub")
 
+    def trmm_lower_kt(self, minv, kt, vt):
+        """vt[m_pad, n_pad] = kt minv^T (= (minv ks)^T) from the test-point-major cross-covariance kt[m_pad, n_pad]."""
+        self._chk(minv, kt, vt)
+        _lib.check(self.lib.pg_trmm_lower_kt(self.h, _code(kt.dtype), kt.shape[1], kt.shape[0], _p(minv), minv.stride(0),
+                                             _p(kt), kt.stride(0), _p(vt), vt.stride(0), self._st()), "pg_trmm_lower_kt")
+
+    def syrk_nt_sub_batched(self, vt_all, c_all, lower_only=True):
+        """c_all[e] -= vt_all[e] vt_all[e]^T for all experts in one launch: vt_all [nexp, m_pad, n_pad], c_all [nexp, m_pad, m_pad]."""
+        self._chk(vt_all, c_all)
+        assert vt_all.dim() == 3 and c_all.dim() == 3 and vt_all.shape[0] == c_all.shape[0]
+        _lib.check(self.lib.pg_syrk_nt_sub_batched(self.h, _code(c_all.dtype), c_all.shape[1], vt_all.shape[2], _p(vt_all),
+                                                   vt_all.stride(1), vt_all.stride(0), _p(c_all), c_all.stride(1), c_all.stride(0),
+                                                   c_all.shape[0], int(lower_only), self._st()), "pg_syrk_nt_sub_batched")
+
     # -- grBCM --------------------------------------------------------------------------------
     def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out, beta=None, prec=None):
         self._chk(mean_c, var_c, var_g, out, beta, prec)
@@ -339,6 +364,17 @@ class HipOps:
         out = self.empty(n, n, dtype=a_pad.dtype)
         self.lauum(minv, out)
         return out, info
+
+    def spd_inverse_lower_batched(self, a_all):
+        """a_all [nexp, n_pad, n_pad] (padded SPD, lower triangles valid; overwritten) -> (the inverses' lower triangles IN a_all,
+        info [nexp]): every step of factor, L^-1 and L^-T L^-1 is one launch over all matrices."""
+        nexp, n = a_all.shape[0], a_all.shape[1]
+        invd = self.empty(nexp, self.potrf_worksize(n, a_all.dtype), dtype=a_all.dtype)
+        info = torch.zeros(nexp, dtype=torch.int32, device=self.device)
+        minv = self.empty(nexp, n, n, dtype=a_all.dtype)
+        self.potrf_trtri_batched(a_all, invd, info, minv)
+        self.lauum_batched(minv, a_all)
+        return a_all, info
 
     def sqdist_argmin(self, x, centres, dist=None, idx=None):
         """dist[n, m] = squared distances, idx[n] (int32) = nearest centre; either output may be None."""

@@ -655,6 +655,29 @@ int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, 
              pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc, lower_only));
 }
 
+int pg_trmm_lower_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Kt, long ldkt,
+                     void* Vt, long ldvt, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Minv && Kt && Vt, "null pointer");
+    NEED(ldm >= n_pad && ldkt >= n_pad && ldvt >= n_pad && Kt != Vt, "bad leading dimension / aliasing");
+    DISPATCH(dtype,
+             pg_trmm_lower_kt_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Minv, ldm, (const double*)Kt, ldkt, (double*)Vt, ldvt),
+             pg_trmm_lower_kt_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Minv, ldm, (const float*)Kt, ldkt, (float*)Vt, ldvt));
+}
+
+int pg_syrk_nt_sub_batched(pg_handle h, int dtype, int m_pad, int n_pad, const void* Vt, long ldvt, long vt_stride, void* C, long ldc,
+                           long c_stride, int nexp, int lower_only, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Vt && C, "null pointer");
+    NEED(nexp >= 1 && nexp <= 65535, "1 <= nexp <= 65535");
+    NEED(ldvt >= n_pad && ldc >= m_pad, "bad leading dimension");
+    NEED(nexp == 1 || (vt_stride >= (long)m_pad * ldvt && c_stride >= (long)m_pad * ldc), "experts' matrices overlap");
+    AtomicGuard ag(h, C);
+    DISPATCH(dtype,
+             pg_syrk_nt_sub_t<double>(h, ST(stream), m_pad, n_pad, (const double*)Vt, ldvt, vt_stride, (double*)C, ldc, c_stride, nexp, lower_only),
+             pg_syrk_nt_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)Vt, ldvt, vt_stride, (float*)C, ldc, c_stride, nexp, lower_only));
+}
+
 int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
                          int is_first, int accumulate, double* out, long ldo, double* beta_out, double* prec_out,
                          void* stream) {
@@ -866,7 +889,7 @@ int pg_gemm_raw(pg_handle h, int dtype, int variant, int M, int N, int K, double
     NEED(h && A && B && C, "null pointer");
     NEED(variant == GEMM_NT_128 || variant == GEMM_NT_RP || variant == GEMM_NN_128 || variant == GEMM_TN_128 ||
              variant == GEMM_TT_128 || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_NT_32x64 ||
-             variant == GEMM_NT_32x128 || variant == GEMM_TT_64 || variant == GEMM_NT_32x32,
+             variant == GEMM_NT_32x128 || variant == GEMM_TT_64 || variant == GEMM_NT_32x32 || variant == GEMM_TN_64,
          "variant not exposed");
     AtomicGuard ag(h, C);
     DISPATCH(dtype, gemm_raw_t<double>(h, variant, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, klo, khi, stream),

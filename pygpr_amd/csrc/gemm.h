@@ -42,6 +42,7 @@ enum GemmVariant {
     GEMM_NT_32x128 = 9, // CU: half the row tile (and a 32-deep K tile) puts two waves on every SIMD (45 % -> MFMA use)
     GEMM_TT_64 = 10,    // TT with 64 x 64 tiles: the small levels of the triangular inverse (few, long 128 x 128 tiles otherwise)
     GEMM_NT_128_SS = 12, // the same epilogue on C = A B^T: the cross-covariance stored test-point-major (K-contiguous B operand)
+    GEMM_TN_64 = 13,    // TN with 64 x 64 tiles: K** - V^T V for a few thousand test points (136 lower 128 x 128 tiles leave most CUs idle)
     GEMM_NT_32x32 = 11  // NT with 32 x 32 tiles and a 64-deep K tile: the chain's U product in the chain-bound tail of the Cholesky
                         // (latency per launch, not throughput, is what counts there: 4x the workgroups, half the K iterations)
 };

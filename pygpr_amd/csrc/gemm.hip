@@ -402,9 +402,9 @@ template <typename T> static int launch_mixed(hipStream_t st, const GemmP<T>& p,
 
 double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi, int batch) {
     const int BM = (variant == GEMM_NT_32x64 || variant == GEMM_NT_32x128 || variant == GEMM_NT_32x32) ? 32
-                   : ((variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_TT_64) ? 64 : 128);
+                   : ((variant == GEMM_NT_RP || variant == GEMM_NT_64 || variant == GEMM_NT_64x128 || variant == GEMM_TT_64 || variant == GEMM_TN_64) ? 64 : 128);
     const int BN = (variant == GEMM_NT_RP) ? 256
-                   : ((variant == GEMM_NT_64 || variant == GEMM_NT_32x64 || variant == GEMM_TT_64) ? 64
+                   : ((variant == GEMM_NT_64 || variant == GEMM_NT_32x64 || variant == GEMM_TT_64 || variant == GEMM_TN_64) ? 64
                       : (variant == GEMM_NT_32x32 ? 32 : 128));
     const int tm = M / BM, tn = N / BN;
     double f = 0;
@@ -469,6 +469,7 @@ template <typename T> int pg_gemm(pg_ctx* ctx, hipStream_t st, int variant_in, c
         // capped the chain's panel solve at a third of its CUs' rate
         case GEMM_NT_32x128: rc = launch<T, false, true, 32, 128, 0, (sizeof(T) == 8 ? 16 : 32)>(st, p); break;
         case GEMM_TT_64: rc = launch<T, true, true, 64, 64, 0>(st, p); break;
+        case GEMM_TN_64: rc = launch<T, true, false, 64, 64, 0>(st, p); break;
         case GEMM_NT_32x32: rc = launch<T, false, true, 32, 32, 0, 64>(st, p); break;
         default: pg_set_error("pg_gemm: unknown variant %d", variant); return -2;
     }

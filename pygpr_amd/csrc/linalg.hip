@@ -1159,13 +1159,46 @@ int pg_trmm_lower_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* M, long 
     return pg_gemm<T>(ctx, st, GEMM_NN_128, p);
 }
 
+// The same two products with the cross-covariance held test-point-major (round 4): Vt[m x n] = Kt Minv^T reads both operands along k
+// (the NT form; K range ends with the tile COLUMN), and C_e -= Vt_e Vt_e^T is the NT rank-n update -- for nexp experts in one launch,
+// so that the few tiles of an m x m output (136 lower 128 x 128 tiles at m = 2048) fill the chip together.
+template <typename T>
+int pg_trmm_lower_kt_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* M, long ldm, const T* Kt, long ldkt, T* Vt, long ldvt) {
+    if (n % PG_PAD || m % 128) { pg_set_error("pg_trmm_lower_kt: n_pad=%d m_pad=%d not aligned", n, m); return -2; }
+    GemmP<T> p = gp0<T>();
+    p.M = m; p.N = n; p.K = n; p.A = Kt; p.lda = ldkt; p.B = M; p.ldb = ldm; p.C = Vt; p.ldc = ldvt; p.khi = 2;
+    return pg_gemm<T>(ctx, st, GEMM_NT_128, p);
+}
+
+template <typename T>
+int pg_syrk_nt_sub_t(pg_ctx* ctx, hipStream_t st, int m, int n, const T* Vt, long ldvt, long evt, T* C, long ldc, long ec, int nexp,
+                     int lower_only) {
+    if (n % 16 || m % 128) { pg_set_error("pg_syrk_nt_sub: m_pad=%d n_pad=%d not aligned", m, n); return -2; }
+    GemmP<T> p = gp0<T>();
+    p.M = p.N = m; p.K = n; p.A = Vt; p.lda = ldvt; p.B = Vt; p.ldb = ldvt; p.C = C; p.ldc = ldc;
+    p.alpha = (T)-1; p.beta = (T)1; p.tri = lower_only ? 1 : 0;
+    p.nexp = nexp; p.eA = evt; p.eB = evt; p.eC = ec;
+    static const int t64 = getenv("PG_SYRK_NT64") ? atoi(getenv("PG_SYRK_NT64")) : 2;   // 2: 128 x 128 tiles below this many slots' worth, 0 / 1: never / always quarter tiles
+    const long tm = m / 128, tiles = (lower_only ? tm * (tm + 1) / 2 : tm * tm) * nexp;
+    const long slots = ctx && ctx->ncu > 0 ? 2L * ctx->ncu : 512;
+    // one expert: quarter tiles while the 128 x 128 tiles do not fill one round of slots (beyond that the mixed launch of pg_gemm ends
+    // whole rounds with quarter tiles by itself); several experts (no mixed launch): up to four rounds' worth
+    const bool quarter = t64 == 1 || (t64 == 2 && (nexp == 1 ? 4 * tiles < 3 * slots : tiles < 4 * slots));
+    return pg_gemm<T>(ctx, st, quarter ? GEMM_NT_64 : GEMM_NT_128, p);
+}
+
 template <typename T>
 int pg_syrk_tn_sub_t(pg_ctx* ctx, hipStream_t st, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only) {
     if (n % 16 || m % 128) { pg_set_error("pg_syrk_tn_sub: m_pad=%d n_pad=%d not aligned", m, n); return -2; }
     GemmP<T> p = gp0<T>();
     p.M = p.N = m; p.K = n; p.A = V; p.lda = ldv; p.B = V; p.ldb = ldv; p.C = C; p.ldc = ldc;
     p.alpha = (T)-1; p.beta = (T)1; p.tri = lower_only ? 1 : 0;
-    return pg_gemm<T>(ctx, st, GEMM_TN_128, p);
+    // a few thousand test points: the 128 x 128 tiles of the m x m output do not fill the chip once (m = 2048: 136 lower tiles on 512
+    // workgroup slots, 28.7 TFLOP/s) -- quarter tiles then (528 of them)
+    static const int t64 = getenv("PG_SYRK_TN64") ? atoi(getenv("PG_SYRK_TN64")) : 1;
+    const long tm = m / 128, tiles = lower_only ? tm * (tm + 1) / 2 : tm * tm;
+    const bool quarter = t64 && ctx && ctx->ncu > 0 && tiles < 2L * ctx->ncu;
+    return pg_gemm<T>(ctx, st, quarter ? GEMM_TN_64 : GEMM_TN_128, p);
 }
 
 template <typename T>
@@ -1228,6 +1261,8 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
                                            T*, double, T*);                                                            \
     template int pg_trmm_lower_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, T*, long);         \
     template int pg_syrk_tn_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, T*, long, int);                     \
+    template int pg_trmm_lower_kt_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, T*, long);      \
+    template int pg_syrk_nt_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, long, T*, long, long, int, int);  \
     template int pg_grbcm_terms_t<T>(hipStream_t, int, const T*, const T*, const T*, int, int, double*, long, double*, \
                                      double*);                                                                         \
     template int pg_grbcm_finish_t<T>(hipStream_t, int, const double*, long, const T*, const T*, T*, T*, double*,     \

@@ -28,6 +28,7 @@ _CHUNK = 8192  # test points per device batch
 # up to this padded size; above it the per-step launches no longer matter and each expert takes the single-model schedule with
 # its flag-coupled chain, one after the other.  PG_BATCH_MAX_N overrides (0: never batch).
 _BATCH_MAX_N = int(os.environ.get("PG_BATCH_MAX_N", "12288"))
+_FULL_VT_BYTES = 16 << 30   # predict(var="full"): experts whose V^T fit this together share one rank-n update launch
 _BATCH_EAGER_N = 4096   # batched experts up to this size form L^-1 with the factor even when nobody asked for variances: the
                         # batched inverse + three batched mat-vec launches are cheaper than one substitution sweep per expert
 
@@ -325,8 +326,6 @@ class Exact_GP(GPR):
         m = xpd.shape[0]
         mean = ops.empty(m, dtype=self.dtype)
         var = ops.empty(m, dtype=self.dtype) if want == "diag" else None
-        if want == "full":
-            cov = self._predict_full(e, spec, xpd)
         for s in range(0, m, _CHUNK):
             xq = xpd[s: s + _CHUNK]
             mc = xq.shape[0]
@@ -348,24 +347,40 @@ class Exact_GP(GPR):
                 var[s: s + mc] = vq[:mc]
         if want == "diag":
             return mean, var
-        if want == "full":
-            return mean, cov
         return mean, None
 
-    def _predict_full(self, e, spec, xpd):
-        """K** - K* K^-1 K*^T = K** - V^T V with V = L^-1 K*^T (gpr.py:108-120)."""
+    def _predict_full(self, xqs):
+        """K** - K* K^-1 K*^T = K** - V^T V with V = L^-1 K*^T (gpr.py:108-120) for every expert (expert b at the points xqs[b]): per
+        expert the test-point-major K*, Vt = K* L^-T (both operands read along k) and K**; then ONE rank-n update for all experts
+        -- the 136 lower tiles of one 2048 x 2048 output leave three quarters of the chip idle, eight experts' tiles fill it."""
         ops = get_ops()
-        m = xpd.shape[0]
+        spec, _ = spec_of(self.cov, self._x.shape[-1])
+        experts = self._experts
+        m = xqs[0].shape[0]
         m_pad = pad_to(m)
-        ks = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
-        ops.kernel_build(spec, e.hp, e.x, xpd, ks)
-        v = ops.empty(e.n_pad, m_pad, dtype=self.dtype)
-        ops.trmm_lower(self._minv(e), ks, v)
-        c = ops.empty(m_pad, m_pad, dtype=self.dtype)
-        ops.kernel_build(spec, e.hp, xpd, None, c)      # K** incl. sigma_n^2, padding = identity
-        ops.syrk_tn_sub(v, c, lower_only=True)          # n m^2 flop on the lower tiles (round 4; the full square was twice that),
-        ops.symmetrize(c, m_pad)                        # the upper triangle is the mirror: exactly symmetric, as before
-        return c[:m, :m]
+        item = torch.empty(0, dtype=self.dtype).element_size()
+        c_all = ops.empty(len(experts), m_pad, m_pad, dtype=self.dtype)
+        b = 0
+        while b < len(experts):
+            n_pad = experts[b].n_pad
+            # experts of one padded size share a launch, within 16 GB of Vt
+            cnt = 1
+            while (b + cnt < len(experts) and experts[b + cnt].n_pad == n_pad and (cnt + 1) * m_pad * n_pad * item <= _FULL_VT_BYTES):
+                cnt += 1
+            vt = ops.empty(cnt, m_pad, n_pad, dtype=self.dtype)
+            kt = ops.empty(m_pad, n_pad, dtype=self.dtype)
+            for i in range(cnt):
+                e = experts[b + i]
+                ops.kernel_build(spec, e.hp, xqs[b + i], e.x, kt)
+                ops.trmm_lower_kt(self._minv(e), kt, vt[i])
+                ops.kernel_build(spec, e.hp, xqs[b + i], None, c_all[b + i])   # K** incl. sigma_n^2, padding = identity
+            ops.syrk_nt_sub_batched(vt, c_all[b: b + cnt], lower_only=True)     # n m^2 flop per expert, lower tiles
+            b += cnt
+        out = []
+        for i in range(len(experts)):
+            ops.symmetrize(c_all[i], m_pad)                 # the upper triangle is the mirror: exactly symmetric
+            out.append(c_all[i][:m, :m])
+        return out
 
     def _predict_device(self, xpd, want):
         """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points: xpd [m, d]
@@ -375,12 +390,15 @@ class Exact_GP(GPR):
         self.update()
         if xpd.dim() == 3 and xpd.shape[0] not in (1, len(self._experts)):
             raise RuntimeError("batch dimension of xp (%d) does not match the %d experts" % (xpd.shape[0], len(self._experts)))
-        means, covs = [], []
+        means, covs, xqs = [], [], []
         for b, e in enumerate(self._experts):
             xq = xpd if xpd.dim() == 2 else xpd[b % xpd.shape[0]]
             mu, cv = self._predict_expert(b, e, xq, want)
             means.append(mu)
             covs.append(cv)
+            xqs.append(xq)
+        if want == "full":
+            covs = self._predict_full(xqs)
         return means, covs
 
     def predict(self, xp: Tensor, var: str = "full") -> Sequence[Tensor]:

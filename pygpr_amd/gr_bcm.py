@@ -14,6 +14,8 @@ batch there is ONE all-reduce(sum) of the [3, m] fp64 buffer (sum beta_c, sum be
 sum beta_c prec_c mu_c).  `GRBCM_MLE` is the shared-hyper-parameter training objective sum_c NLML_c (one
 all-reduce of [1 + nhp]); it replaces the reference's dead `GRBCM.train` (gr_bcm.py:36-97 raises).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -21,6 +23,10 @@ import torch.distributed as dist
 from ._ops import get_ops, pad_to
 from .gpr import GPR, Exact_GP, _checked, _lin_alg_error
 from .loss import MLE, Loss
+
+# aggregate_full_covar: the owned experts' m x m covariances are inverted in ONE batched call per step up to this padded size
+# (PG_AGG_BATCH_MAX overrides; 0: one expert after the other)
+_AGG_BATCH_MAX = int(os.environ.get("PG_AGG_BATCH_MAX", "4096"))
 
 
 def _dist_on(flag):
@@ -153,12 +159,15 @@ class GRBCM(GPR):
         self.beta, self.prec, self._sums = beta, prec, sums
         return mean, var
 
-    def _padded_spd(self, cov):
-        """m x m covariance -> padded device copy with a unit diagonal in the padding."""
+    def _padded_spd(self, cov, out=None):
+        """m x m covariance -> padded device copy with a unit diagonal in the padding (into `out` [m_pad, m_pad] if given)."""
         ops = get_ops()
         m = cov.shape[0]
         mp = pad_to(m)
-        a = ops.zeros(mp, mp, dtype=cov.dtype)
+        if out is None or mp > m:
+            a = ops.zeros(mp, mp, dtype=cov.dtype) if out is None else out.zero_()
+        else:
+            a = out
         a[:m, :m] = cov
         if mp > m:
             a.diagonal()[m:] = 1.0
@@ -176,22 +185,37 @@ class GRBCM(GPR):
         self._aggregate_device(mean_g, var_g, means_l, vars_l)       # fills self._sums, beta, prec
         state = {}
 
+        mp = pad_to(m)
+        # the owned experts' m x m inversions in ONE batched call per step (round 4: eight 2048 x 2048 inversions 9.8 -> about 3 ms)
+        # while the matrices are small enough for the batched schedule to win (gpr.py's rule for batched fits)
+        together = 2 <= len(covs_l) and mp <= _AGG_BATCH_MAX
+
         def enqueue():
             acc = None
             infos = []
-            for c, cov_c in enumerate(covs_l):
-                pc, info = ops.spd_inverse_lower(self._padded_spd(cov_c))
-                infos.append(info)
-                if acc is None:
-                    acc = ops.empty(pc.shape[0], pc.shape[0], dtype=pc.dtype)
-                ops.grbcm_weighted_prec(pc, self.beta[c + 1].contiguous(), acc, m, c > 0)
+            if together:
+                stack = ops.empty(len(covs_l), mp, mp, dtype=cov_g.dtype)
+                for c, cov_c in enumerate(covs_l):
+                    self._padded_spd(cov_c, out=stack[c])
+                _, info_all = ops.spd_inverse_lower_batched(stack)
+                acc = ops.empty(mp, mp, dtype=cov_g.dtype)
+                for c in range(len(covs_l)):
+                    ops.grbcm_weighted_prec(stack[c], self.beta[c + 1].contiguous(), acc, m, c > 0)
+                infos = [info_all]
+            else:
+                for c, cov_c in enumerate(covs_l):
+                    pc, info = ops.spd_inverse_lower(self._padded_spd(cov_c))
+                    infos.append(info)
+                    if acc is None:
+                        acc = ops.empty(pc.shape[0], pc.shape[0], dtype=pc.dtype)
+                    ops.grbcm_weighted_prec(pc, self.beta[c + 1].contiguous(), acc, m, c > 0)
             if acc is None:
                 acc = self._padded_spd(torch.zeros(m, m, dtype=cov_g.dtype, device=cov_g.device))
                 acc.diagonal()[:m] = 0.0
             state["acc"], state["infos"] = acc, infos
 
         def local_infos():
-            return [int(i.item()) for i in state["infos"]]
+            return [int(v) for i in state["infos"] for v in i.reshape(-1).tolist()]
 
         # the m x m inverses of the owned experts are rank-local: a timed-out coupled chain is repaired here, before the collective
         local = _checked(enqueue, local_infos)

@@ -216,6 +216,14 @@ class OracleOps:
         vv = _np(v).astype(np.float64)
         c -= torch.from_numpy(vv.T @ vv)
 
+    def trmm_lower_kt(self, minv, kt, vt):
+        vt.copy_(torch.from_numpy(_np(kt).astype(np.float64) @ np.tril(_np(minv).astype(np.float64)).T))
+
+    def syrk_nt_sub_batched(self, vt_all, c_all, lower_only=True):
+        for e in range(vt_all.shape[0]):
+            vv = _np(vt_all[e]).astype(np.float64)
+            c_all[e] -= torch.from_numpy(vv @ vv.T)
+
     # grBCM
     def grbcm_local_terms(self, mean_c, var_c, var_g, is_first, accumulate, out, beta=None, prec=None):
         t = orc.grbcm_terms(_np(mean_c).astype(np.float64), _np(var_c).astype(np.float64), _np(var_g).astype(np.float64), is_first)
@@ -263,6 +271,14 @@ class OracleOps:
         out = torch.zeros_like(a_pad)
         self.lauum(minv, out)
         return out, info
+
+    def spd_inverse_lower_batched(self, a_all):
+        info = torch.zeros(a_all.shape[0], dtype=torch.int32)
+        for e in range(a_all.shape[0]):
+            out, i = self.spd_inverse_lower(a_all[e].clone())
+            a_all[e].copy_(out)
+            info[e] = i[0]
+        return a_all, info
 
     def sqdist_argmin(self, x, centres, dist=None, idx=None):
         xx, cc = _np(x).astype(np.float64), _np(centres).astype(np.float64)

@@ -108,6 +108,30 @@ def test_gemm_skinny_chain_variants(ops):
         np.testing.assert_allclose(host(c), c0 - a @ b.T, atol=tol)
 
 
+def test_syrk_tn_quarter_tiles_same_bits(ops):
+    """K** - V^T V on 64 x 64 tiles (GEMM_TN_64: outputs whose 128 x 128 tiles do not fill the chip) gives the bits of the 128 x 128
+    launch: an element's k order does not depend on the tile shape; pg_syrk_tn_sub picks the quarter tiles by itself."""
+    from pygpr_amd._lib import GEMM_TN, GEMM_TN_64
+
+    rng = np.random.default_rng(17)
+    m, k = 384, 272
+    v = rng.standard_normal((k, m))
+    c0 = rng.standard_normal((m, m))
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-3)):
+        outs = []
+        for variant in (GEMM_TN, GEMM_TN_64):
+            c = dev(c0, dt)
+            ops.gemm_raw(variant, m, m, k, -1.0, dev(v, dt), dev(v, dt), 1.0, c, tri=1)
+            outs.append(host(c))
+        low = np.tril_indices(m)
+        np.testing.assert_allclose(outs[1][low], (c0 - v.T @ v)[low], atol=tol)
+        assert np.array_equal(outs[0][low], outs[1][low])
+        assert np.array_equal(np.triu(outs[1], 128), np.triu(host(dev(c0, dt)), 128))   # tiles above the diagonal untouched
+        c = dev(c0, dt)
+        ops.syrk_tn_sub(dev(v, dt), c, lower_only=True)
+        assert np.array_equal(host(c)[low], outs[0][low])
+
+
 def test_gemm_triangular_k_ranges(ops):
     from pygpr_amd._lib import GEMM_NN, GEMM_TN
 
@@ -780,6 +804,21 @@ def test_predict_mean_q(ops):
     ops.syrk_tn_sub(v, c)
     _, cov_ref = orc.gp_predict(covs, hp, x, y, xp, "full", form="direct")
     np.testing.assert_allclose(np.tril(host(c)[:m, :m]), np.tril(cov_ref), atol=1e-11)
+    # the same pieces from the test-point-major cross-covariance (what the class surface uses): Vt = Kt Minv^T, and the rank-n update
+    # of several experts' outputs in one launch (here: the same expert three times, one of them with a scaled Vt)
+    vt = ops.empty(mpad, npad)
+    ops.trmm_lower_kt(minv, kt, vt)
+    np.testing.assert_allclose(host(vt), host(v).T, atol=1e-12)
+    vt_all = torch.stack([vt, 0.5 * vt, vt])
+    c_all = ops.zeros(3, mpad, mpad)
+    c_all[:, :m, :m] = dev(orc.kernel(covs, hp, xp, form="direct"))
+    c_keep = host(c_all[1]).copy()
+    ops.syrk_nt_sub_batched(vt_all, c_all)
+    for e in (0, 2):
+        np.testing.assert_allclose(np.tril(host(c_all[e])[:m, :m]), np.tril(cov_ref), atol=1e-11)
+    assert np.array_equal(host(c_all[0]), host(c_all[2]))
+    np.testing.assert_allclose(np.tril(host(c_all[1])), np.tril(c_keep - 0.25 * host(v).T @ host(v)), atol=1e-11)
+    assert np.array_equal(np.triu(host(c_all[1]), 128), np.triu(c_keep, 128))          # tiles above the diagonal are not touched
 
 
 def test_grbcm_terms(ops):

@@ -313,6 +313,32 @@ def test_grbcm_golden(golden):
             assert torch.equal(cov_f, cov_f.T)
 
 
+def test_grbcm_full_covariance_batched_inversions_match_one_by_one(monkeypatch):
+    """aggregate_full_covar (gr_bcm.py:99-114): the experts' m x m inversions as ONE batched call per step (default) against one
+    expert after the other (PG_AGG_BATCH_MAX=0), m = 300 test points (padded to 384), and both against the oracle's aggregation."""
+    from pygpr_amd import gr_bcm as _g
+
+    rng = np.random.default_rng(91)
+    nc, n, ng, d, m = 5, 200, 60, 3, 300
+    xl, xg, xs = rng.random((nc, n, d)), rng.random((ng, d)), rng.random((m, d))
+    yl, yg = np.sin(xl.sum(-1)), np.sin(xg.sum(-1))
+    hp = np.concatenate([[1.0], np.full(d, 0.7), [0.05]])
+    outs = []
+    for lim in (4096, 0):
+        monkeypatch.setattr(_g, "_AGG_BATCH_MAX", lim)
+        gm = pg.GRBCM(T(xl), T(yl), T(xg), T(yg), se_wn())
+        gm.gpg.set_params(T(hp))
+        gm.set_local_params(T(hp))
+        mu, cov = gm.predict(T(xs), var="full")
+        assert torch.equal(cov, cov.T)
+        outs.append((N(mu), N(cov)))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-8, atol=1e-12)
+    mu_o, cov_o = orc.grbcm_predict([orc.SE, orc.WN], hp, np.tile(hp, (nc, 1)), xl, yl, xg, yg, xs, "full")
+    np.testing.assert_allclose(outs[0][1], cov_o, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(outs[0][0], mu_o, rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("ng,nc,n,d", [(10, 2, 10, 2), (100, 5, 50, 3), (100, 10, 100, 7)])
 def test_grbcm_reproduces_targets(ng, nc, n, d):
     """test_grbcm.py:18-37 restated: predicting one local shard reproduces sin(sum x)."""
