@@ -219,12 +219,13 @@ int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv
 int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, long ldv, void* C, long ldc,
                    int lower_only, void* stream);
 /* The same two steps from the cross-covariance stored test-point-major, Kt[m_pad x n_pad] = k(Xp, X) (round 4; what Exact_GP.predict and
- * GRBCM.predict use for var="full", gpr.py:108-120, gr_bcm.py:151-155): Vt[m_pad x n_pad] = Kt Minv^T = (Minv Ks)^T, both operands read
- * along k, and C_e = C_e - Vt_e Vt_e^T on m_pad x m_pad for nexp experts in ONE launch (expert e at Vt + e vt_stride, C + e c_stride
- * elements) -- the tiles of one small m x m output do not fill the chip, those of a committee's experts together do.  Same results as
- * pg_trmm_lower / pg_syrk_tn_sub to rounding. */
-int pg_trmm_lower_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Kt, long ldkt,
-                     void* Vt, long ldvt, void* stream);
+ * GRBCM.predict use for var="full", gpr.py:108-120, gr_bcm.py:151-155), for the nexp experts of a batched model in ONE launch each
+ * (expert e at base + e * stride elements; a stride of 0 shares an operand): Vt_e[m_pad x n_pad] = Kt_e Minv_e^T = (Minv_e Ks_e)^T, both
+ * operands read along k, and C_e = C_e - Vt_e Vt_e^T on m_pad x m_pad.  The tiles of one expert's triangular product pack badly onto the
+ * chip (very different lengths) and those of one small m x m output do not fill it; a committee's experts together do both.  Same
+ * results as pg_trmm_lower / pg_syrk_tn_sub to rounding. */
+int pg_trmm_lower_kt_batched(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, long m_stride, const void* Kt,
+                             long ldkt, long kt_stride, void* Vt, long ldvt, long vt_stride, int nexp, void* stream);
 int pg_syrk_nt_sub_batched(pg_handle h, int dtype, int m_pad, int n_pad, const void* Vt, long ldvt, long vt_stride, void* C, long ldc,
                            long c_stride, int nexp, int lower_only, void* stream);
 

@@ -59,7 +59,7 @@ _SIGS = {
     "pg_predict_mean_q_kt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _d, _vp, _vp]),
     "pg_trmm_lower": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "pg_syrk_tn_sub": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
-    "pg_trmm_lower_kt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "pg_trmm_lower_kt_batched": (_i, [_vp, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp]),
     "pg_syrk_nt_sub_batched": (_i, [_vp, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _i, _vp]),
     "pg_grbcm_local_terms": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "pg_grbcm_finish": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

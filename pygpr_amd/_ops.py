@@ -312,10 +312,23 @@ class HipOps:
                                            c.stride(0), int(lower_only), self._st()), "pg_syrk_tn_sub")
 
     def trmm_lower_kt(self, minv, kt, vt):
-        """vt[m_pad, n_pad] = kt minv^T (= (minv ks)^T) from the test-point-major cross-covariance kt[m_pad, n_pad]."""
-        self._chk(minv, kt, vt)
-        _lib.check(self.lib.pg_trmm_lower_kt(self.h, _code(kt.dtype), kt.shape[1], kt.shape[0], _p(minv), minv.stride(0),
-                                             _p(kt), kt.stride(0), _p(vt), vt.stride(0), self._st()), "pg_trmm_lower_kt")
+        """vt = kt minv^T (= (minv ks)^T) from the test-point-major cross-covariance: kt, vt [m_pad, n_pad] or [nexp, m_pad, n_pad];
+        minv [n_pad, n_pad], [nexp, n_pad, n_pad], or a list of nexp matrices that sit at one stride in memory (views of a stack)."""
+        if isinstance(minv, (list, tuple)):
+            self._chk(kt, vt, *minv)
+            m0 = minv[0]
+            step = (minv[1].data_ptr() - m0.data_ptr()) // m0.element_size() if len(minv) > 1 else 0
+            assert all(mi.data_ptr() - m0.data_ptr() == i * step * m0.element_size() and mi.stride(0) == m0.stride(0)
+                       for i, mi in enumerate(minv)), "the experts' inverses do not sit at one stride"
+            ldm = m0.stride(0)
+        else:
+            self._chk(minv, kt, vt)
+            m0, ldm, step = minv, minv.stride(-2), (minv.stride(0) if minv.dim() == 3 else 0)
+        nexp = kt.shape[0] if kt.dim() == 3 else 1
+        _lib.check(self.lib.pg_trmm_lower_kt_batched(
+            self.h, _code(kt.dtype), kt.shape[-1], kt.shape[-2], _p(m0), ldm, step, _p(kt), kt.stride(-2),
+            kt.stride(0) if kt.dim() == 3 else 0, _p(vt), vt.stride(-2), vt.stride(0) if vt.dim() == 3 else 0, nexp, self._st()),
+            "pg_trmm_lower_kt_batched")
 
     def syrk_nt_sub_batched(self, vt_all, c_all, lower_only=True):
         """c_all[e] -= vt_all[e] vt_all[e]^T for all experts in one launch: vt_all [nexp, m_pad, n_pad], c_all [nexp, m_pad, m_pad]."""

@@ -655,14 +655,18 @@ int pg_syrk_tn_sub(pg_handle h, int dtype, int m_pad, int n_pad, const void* V, 
              pg_syrk_tn_sub_t<float>(h, ST(stream), m_pad, n_pad, (const float*)V, ldv, (float*)C, ldc, lower_only));
 }
 
-int pg_trmm_lower_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Kt, long ldkt,
-                     void* Vt, long ldvt, void* stream) {
+int pg_trmm_lower_kt_batched(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, long m_stride, const void* Kt, long ldkt,
+                             long kt_stride, void* Vt, long ldvt, long vt_stride, int nexp, void* stream) {
     JOIN(h, stream);
     NEED(h && Minv && Kt && Vt, "null pointer");
+    NEED(nexp >= 1 && nexp <= 65535, "1 <= nexp <= 65535");
     NEED(ldm >= n_pad && ldkt >= n_pad && ldvt >= n_pad && Kt != Vt, "bad leading dimension / aliasing");
+    NEED(nexp == 1 || vt_stride >= (long)m_pad * ldvt, "experts' outputs overlap");
     DISPATCH(dtype,
-             pg_trmm_lower_kt_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Minv, ldm, (const double*)Kt, ldkt, (double*)Vt, ldvt),
-             pg_trmm_lower_kt_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Minv, ldm, (const float*)Kt, ldkt, (float*)Vt, ldvt));
+             pg_trmm_lower_kt_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Minv, ldm, m_stride, (const double*)Kt, ldkt, kt_stride,
+                                        (double*)Vt, ldvt, vt_stride, nexp),
+             pg_trmm_lower_kt_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Minv, ldm, m_stride, (const float*)Kt, ldkt, kt_stride,
+                                       (float*)Vt, ldvt, vt_stride, nexp));
 }
 
 int pg_syrk_nt_sub_batched(pg_handle h, int dtype, int m_pad, int n_pad, const void* Vt, long ldvt, long vt_stride, void* C, long ldc,

@@ -50,7 +50,8 @@ int pg_predict_mean_q_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* Kt, long
                         T* mean, T* q, double kss, T* work);
 template <typename T> int pg_trmm_lower_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, const T* Ks, long ldks, T* V, long ldv);
 template <typename T> int pg_syrk_tn_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only);
-template <typename T> int pg_trmm_lower_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, const T* Kt, long ldkt, T* Vt, long ldvt);
+template <typename T> int pg_trmm_lower_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, long em, const T* Kt, long ldkt, long ekt, T* Vt,
+                                             long ldvt, long evt, int nexp);
 template <typename T> int pg_syrk_nt_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* Vt, long ldvt, long evt, T* C, long ldc, long ec, int nexp,
                                            int lower_only);
 template <typename T>

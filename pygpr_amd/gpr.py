@@ -368,12 +368,19 @@ class Exact_GP(GPR):
             while (b + cnt < len(experts) and experts[b + cnt].n_pad == n_pad and (cnt + 1) * m_pad * n_pad * item <= _FULL_VT_BYTES):
                 cnt += 1
             vt = ops.empty(cnt, m_pad, n_pad, dtype=self.dtype)
-            kt = ops.empty(m_pad, n_pad, dtype=self.dtype)
+            minvs = [self._minv(experts[b + i]) for i in range(cnt)]
+            step = (minvs[1].data_ptr() - minvs[0].data_ptr()) if cnt > 1 else 0
+            stacked = cnt > 1 and step > 0 and all(mi.data_ptr() - minvs[0].data_ptr() == i * step and mi.stride(0) == minvs[0].stride(0)
+                                                   for i, mi in enumerate(minvs))
+            kt = ops.empty(cnt if stacked else 1, m_pad, n_pad, dtype=self.dtype)
             for i in range(cnt):
                 e = experts[b + i]
-                ops.kernel_build(spec, e.hp, xqs[b + i], e.x, kt)
-                ops.trmm_lower_kt(self._minv(e), kt, vt[i])
+                ops.kernel_build(spec, e.hp, xqs[b + i], e.x, kt[i if stacked else 0])
+                if not stacked:
+                    ops.trmm_lower_kt(minvs[i], kt[0], vt[i])
                 ops.kernel_build(spec, e.hp, xqs[b + i], None, c_all[b + i])   # K** incl. sigma_n^2, padding = identity
+            if stacked:      # experts factorised together hold their inverses in one stack: one launch for all the products
+                ops.trmm_lower_kt(minvs, kt, vt)
             ops.syrk_nt_sub_batched(vt, c_all[b: b + cnt], lower_only=True)     # n m^2 flop per expert, lower tiles
             b += cnt
         out = []

@@ -217,6 +217,10 @@ class OracleOps:
         c -= torch.from_numpy(vv.T @ vv)
 
     def trmm_lower_kt(self, minv, kt, vt):
+        if kt.dim() == 3:
+            for e in range(kt.shape[0]):
+                self.trmm_lower_kt(minv[e], kt[e], vt[e])
+            return
         vt.copy_(torch.from_numpy(_np(kt).astype(np.float64) @ np.tril(_np(minv).astype(np.float64)).T))
 
     def syrk_nt_sub_batched(self, vt_all, c_all, lower_only=True):

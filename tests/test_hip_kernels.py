@@ -809,6 +809,15 @@ def test_predict_mean_q(ops):
     vt = ops.empty(mpad, npad)
     ops.trmm_lower_kt(minv, kt, vt)
     np.testing.assert_allclose(host(vt), host(v).T, atol=1e-12)
+    # ... and the products of several experts in one launch: inverses as a stack, or as a list of views at one stride
+    minv3 = torch.stack([minv, 2.0 * minv, minv])
+    kt3 = torch.stack([kt, kt, 0.5 * kt])
+    for mm in (minv3, [minv3[0], minv3[1], minv3[2]]):
+        vt3 = ops.empty(3, mpad, npad)
+        ops.trmm_lower_kt(mm, kt3, vt3)
+        assert np.array_equal(host(vt3[0]), host(vt))
+        np.testing.assert_allclose(host(vt3[1]), 2.0 * host(vt), rtol=1e-15)
+        np.testing.assert_allclose(host(vt3[2]), 0.5 * host(vt), rtol=1e-15)
     vt_all = torch.stack([vt, 0.5 * vt, vt])
     c_all = ops.zeros(3, mpad, mpad)
     c_all[:, :m, :m] = dev(orc.kernel(covs, hp, xp, form="direct"))

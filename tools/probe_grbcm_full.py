@@ -75,6 +75,11 @@ def main():
     vt8[:] = vt
     c8 = ops.zeros(nc, m_pad, m_pad, dtype=g.gpl.dtype)
     t11, _ = timed(lambda: ops.syrk_nt_sub_batched(vt8, c8))
+    minvs = [g.gpl._minv(ee) for ee in g.gpl._experts]
+    kt8 = ops.empty(nc, m_pad, e.n_pad, dtype=g.gpl.dtype)
+    kt8[:] = kt
+    t12, _ = timed(lambda: ops.trmm_lower_kt(minvs, kt8, vt8))
+    print("Vt of %d experts in one launch %.3f ms (%.1f TFLOP/s)" % (nc, t12, nc * float(e.n_pad) ** 2 * m_pad / t12 / 1e9))
     n = e.n_pad
     print("test-point-major forms: K*^T %.3f, Vt = K* L^-T %.3f (%.1f TFLOP/s), rank-n update of one expert %.3f, of %d experts in one launch %.3f "
           "(%.1f TFLOP/s)" % (t8, t9, float(n) ** 2 * m_pad / t9 / 1e9, t10, nc, t11, nc * float(n) * m_pad ** 2 / t11 / 1e9))
