@@ -188,16 +188,19 @@ class GRBCM(GPR):
         mp = pad_to(m)
         # the owned experts' m x m inversions in ONE batched call per step (round 4: eight 2048 x 2048 inversions 9.8 -> about 3 ms)
         # while the matrices are small enough for the batched schedule to win (gpr.py's rule for batched fits)
-        together = 2 <= len(covs_l) and mp <= _AGG_BATCH_MAX
+        # (the global expert's covariance rides along as the last matrix of the batch: it is needed after the all-reduce only, but it is
+        # known now, and one more matrix in the batch costs a fraction of an inversion of its own)
+        together = 1 <= len(covs_l) and mp <= _AGG_BATCH_MAX
 
         def enqueue():
             acc = None
             infos = []
             if together:
-                stack = ops.empty(len(covs_l), mp, mp, dtype=cov_g.dtype)
-                for c, cov_c in enumerate(covs_l):
+                stack = ops.empty(len(covs_l) + 1, mp, mp, dtype=cov_g.dtype)
+                for c, cov_c in enumerate(list(covs_l) + [cov_g]):
                     self._padded_spd(cov_c, out=stack[c])
                 _, info_all = ops.spd_inverse_lower_batched(stack)
+                state["p0"] = stack[len(covs_l)]
                 acc = ops.empty(mp, mp, dtype=cov_g.dtype)
                 for c in range(len(covs_l)):
                     ops.grbcm_weighted_prec(stack[c], self.beta[c + 1].contiguous(), acc, m, c > 0)
@@ -228,10 +231,14 @@ class GRBCM(GPR):
 
         def enqueue2():
             a2 = acc.clone()
-            p0, info0 = ops.spd_inverse_lower(self._padded_spd(cov_g))
+            infos2 = []
+            p0 = state.get("p0")
+            if p0 is None:
+                p0, info0 = ops.spd_inverse_lower(self._padded_spd(cov_g))
+                infos2.append(info0)
             ops.grbcm_weighted_prec(p0, self.beta[0].contiguous(), a2, m, True)
             cov, info1 = ops.spd_inverse_lower(a2)
-            state["cov"], state["infos2"] = cov, [info0, info1]
+            state["cov"], state["infos2"] = cov, infos2 + [info1]
 
         tail = _checked(enqueue2, lambda: [int(i.item()) for i in state["infos2"]])
         cov = state["cov"]
