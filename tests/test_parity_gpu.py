@@ -315,7 +315,7 @@ def test_grbcm_golden(golden):
 
 def test_grbcm_full_covariance_batched_inversions_match_one_by_one(monkeypatch):
     """aggregate_full_covar (gr_bcm.py:99-114): the experts' m x m inversions as ONE batched call per step (default) against one
-    expert after the other (PG_AGG_BATCH_MAX=0), m = 300 test points (padded to 384), and both against the oracle's aggregation."""
+    expert after the other (PG_AGG_BATCH_MAX=0), m = 300 test points (padded to 512), and both against the oracle's aggregation."""
     from pygpr_amd import gr_bcm as _g
 
     rng = np.random.default_rng(91)
@@ -323,17 +323,22 @@ def test_grbcm_full_covariance_batched_inversions_match_one_by_one(monkeypatch):
     xl, xg, xs = rng.random((nc, n, d)), rng.random((ng, d)), rng.random((m, d))
     yl, yg = np.sin(xl.sum(-1)), np.sin(xg.sum(-1))
     hp = np.concatenate([[1.0], np.full(d, 0.7), [0.05]])
+    from pygpr_amd import gpr as _gpr
+
     outs = []
-    for lim in (4096, 0):
+    for lim, vt_bytes in ((4096, _gpr._FULL_VT_BYTES), (0, 1), (4096, 3 * 512 * 512 * 8)):
+        # second pass: every expert's products and update on their own; third: groups of three experts per launch
         monkeypatch.setattr(_g, "_AGG_BATCH_MAX", lim)
+        monkeypatch.setattr(_gpr, "_FULL_VT_BYTES", vt_bytes)
         gm = pg.GRBCM(T(xl), T(yl), T(xg), T(yg), se_wn())
         gm.gpg.set_params(T(hp))
         gm.set_local_params(T(hp))
         mu, cov = gm.predict(T(xs), var="full")
         assert torch.equal(cov, cov.T)
         outs.append((N(mu), N(cov)))
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-8, atol=1e-12)
+    for other in outs[1:]:
+        np.testing.assert_allclose(outs[0][0], other[0], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(outs[0][1], other[1], rtol=1e-8, atol=1e-12)
     mu_o, cov_o = orc.grbcm_predict([orc.SE, orc.WN], hp, np.tile(hp, (nc, 1)), xl, yl, xg, yg, xs, "full")
     np.testing.assert_allclose(outs[0][1], cov_o, rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(outs[0][0], mu_o, rtol=1e-6, atol=1e-9)
