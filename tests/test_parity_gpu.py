@@ -738,6 +738,25 @@ def test_cfg4_size_committee():
     mu, var = g4.predict(xs, var="diag")
     assert float(var.min()) > 0 and float(var.max()) < 1.0 + 0.01 + 1e-6      # prior variance sigma^2 + sigma_n^2
     assert float((mu - T(np.sin(-N(xs).sum(1)))).abs().mean()) < 0.2            # and it predicts the function it was given
+    # (iv) the FULL-covariance committee at this size (gr_bcm.py:99-114,151-155; m = 2048): every expert's Vt and rank-n update in one
+    # launch and nine 2048 x 2048 inversions on the batched coupled chain, against one expert / one inversion after the other;
+    # exactly symmetric and positive definite.  (Its MEAN is not compared with the diag committee's: the reference scales the summed
+    # precision-weighted means by diag(cov_full) -- gr_bcm.py:147 -- which is a different estimator; the golden vectors pin that formula.)
+    from pygpr_amd import gpr as _gpr, gr_bcm as _g
+
+    xf = xs[:2048]
+    mu_f, cov_f = g4.predict(xf, var="full")
+    keep = (_g._AGG_BATCH_MAX, _gpr._FULL_VT_BYTES)
+    try:
+        _g._AGG_BATCH_MAX, _gpr._FULL_VT_BYTES = 0, 1
+        mu_1, cov_1 = g4.predict(xf, var="full")
+    finally:
+        _g._AGG_BATCH_MAX, _gpr._FULL_VT_BYTES = keep
+    assert torch.equal(cov_f, cov_f.T) and bool(torch.isfinite(cov_f).all())
+    scale = float(cov_1.diagonal().mean())
+    assert float((cov_f - cov_1).abs().max()) < 1e-9 * scale and float((mu_f - mu_1).abs().max()) < 1e-9
+    torch.linalg.cholesky(cov_f.cuda())                                          # positive definite (raises otherwise)
+    assert float(cov_f.diagonal().min()) > 0
     del g4
     torch.cuda.empty_cache()
 
