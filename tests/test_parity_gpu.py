@@ -404,6 +404,11 @@ def test_fp32_opt_in():
     mu_ref, var_ref = orc.gp_predict([orc.M52, orc.WN], hp, x, y, xp, "diag")
     np.testing.assert_allclose(N(mu), mu_ref, atol=2e-3)
     np.testing.assert_allclose(N(var), var_ref, atol=2e-3)
+    mu_f, cov_f = gp.predict(T(xp).float(), var="full")        # the test-point-major products in fp32 (gpr.py:108-120)
+    _, cov_ref = orc.gp_predict([orc.M52, orc.WN], hp, x, y, xp, "full")
+    assert cov_f.dtype == torch.float32 and torch.equal(cov_f, cov_f.T)
+    np.testing.assert_allclose(N(cov_f), cov_ref, atol=2e-3)
+    np.testing.assert_allclose(N(mu_f), mu_ref, atol=2e-3)
     loss, grad = pg.MLE(gp).loss_and_grad(hp.copy())
     l_ref, g_ref = orc.mle_loss_and_grad([orc.M52, orc.WN], hp, x, y, "kinv")
     np.testing.assert_allclose(loss, l_ref, rtol=1e-3)
@@ -427,6 +432,13 @@ def test_grbcm_fp32_committee(golden):
                                         g[p + "xg"], g[p + "yg"], g[p + "xs"])[:2]
     np.testing.assert_allclose(N(mu), mu_ref, atol=2e-3)
     np.testing.assert_allclose(N(var), var_ref, rtol=2e-2, atol=1e-4)
+    # the full-covariance committee in fp32: batched products and batched m x m inversions (gr_bcm.py:99-114)
+    mu_f, cov_f = m.predict(f32(g[p + "xs"]), var="full")
+    mu_fr, cov_fr = orc.grbcm_predict([orc.M52, orc.WN], hp, np.broadcast_to(hp, (nc, hp.size)), g[p + "xl"], g[p + "yl"],
+                                      g[p + "xg"], g[p + "yg"], g[p + "xs"], "full")
+    assert cov_f.dtype == torch.float32 and torch.equal(cov_f, cov_f.T)
+    np.testing.assert_allclose(N(cov_f), cov_fr, rtol=5e-2, atol=5e-4)
+    np.testing.assert_allclose(N(mu_f), mu_fr, rtol=5e-2, atol=5e-3)
     loss, grad = pg.GRBCM_MLE(m).loss_and_grad(hp.copy())
     x, y = orc.grbcm_data(g[p + "xl"], g[p + "yl"], g[p + "xg"], g[p + "yg"])
     ref = [orc.mle_loss_and_grad([orc.M52, orc.WN], hp, x[c], y[c], "kinv") for c in range(nc)]
