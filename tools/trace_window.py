@@ -47,3 +47,12 @@ for k in win:
 for o in out:
     if o[3] > 30000 or o[2] == 1 and o[3] > 15000:
         print("  @%.3f  %-18s q%-3s x%-3d busy %.3f ms  until %.3f  (first launch %d workgroups)" % ((o[1] - mixed[1]) / 1e6, o[0][0], o[0][1], o[2], o[3] / 1e6, (o[4] - mixed[1]) / 1e6, o[5]))
+# what else ran while each product of 4096 tiles (and the mixed update) ran: other kernels overlapping its interval
+print("kernels overlapping the large products of evaluation %d:" % E)
+for big in [k for k in seg if (k[3] == 4096 or k[2] == 'gMIXED') and k[1] - k[0] > 2e6]:
+    others = [k for k in seg if k is not big and k[0] < big[1] and k[1] > big[0]]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for k in others:
+        a = agg[(k[2], k[4])]; a[0] += 1; a[1] += (min(k[1], big[1]) - max(k[0], big[0])) / 1e6
+    print("  %-14s @%.2f +%.3f ms (queue %s): %s" % (big[2], (big[0] - t0) / 1e6, (big[1] - big[0]) / 1e6, big[4],
+          ", ".join("%s q%s x%d %.3f ms" % (n, q, c, t) for (n, q), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])) or "nothing"))
