@@ -62,13 +62,50 @@ def default_hp(d):
     return np.concatenate([[1.0], np.ones(d), [0.1]])            # sigma, l_1..l_d, sigma_n
 
 
+def host_cpu_share():
+    """What this process may actually use of the host: CPUs in its affinity mask, the cgroup's CPU quota (v2 cpu.max or v1
+    cfs_quota), physical cores.  A box that shows 128 logical CPUs but grants a 16-CPU quota throttles 128 spinning LAPACK threads
+    -- rounds 2-4 let torch pick its default thread count and the same evaluation took 40 / 64 / 86 s."""
+    info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_cpu_quota": None, "physical_cores": None}
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                info["cgroup_cpu_quota"] = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    info["cgroup_cpu_quota"] = q / per
+        except Exception:
+            pass
+    try:
+        import psutil
+        info["physical_cores"] = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    return info
+
+
 def cpu_baseline(x_full, y_full, hp, n_small, gpu_loss, gpu_grad, full_size):
-    """Oracle (kind = "port"), lean K^-1 route, all host cores: min of 2 at n_small, and one measured evaluation on
-    the GPU's own data at full size, whose NLML / gradient are compared with the GPU's."""
+    """Oracle (kind = "port"), lean K^-1 route on the host cores this process is granted: min of 2 at n_small, and -- on the GPU's own
+    data at full size -- min of 2 measured evaluations (both reported; the second is skipped when the first took more than 75 s),
+    whose NLML / gradient are compared with the GPU's.  Reproducibility (round 5): the thread count is FIXED to what the process may
+    use (min of affinity mask, cgroup quota, physical cores; PG_BENCH_CPU_THREADS overrides) and recorded with the load average."""
     from oracle import pygpr_oracle as orc
 
     n_full, d = x_full.shape
+    share = host_cpu_share()
+    cand = [v for v in (share["affinity_cpus"], share["cgroup_cpu_quota"], share["physical_cores"]) if v]
+    threads_default = torch.get_num_threads()
+    threads = int(os.environ.get("PG_BENCH_CPU_THREADS", "0"))
+    if threads <= 0:
+        threads = max(1, int(min(cand))) if cand else threads_default
+    torch.set_num_threads(threads)
     cores = torch.get_num_threads()          # intra-op threads the baseline actually used
+    load0 = os.getloadavg() if hasattr(os, "getloadavg") else None
     orc.mle_loss_and_grad_lean(hp, x_full[:512], y_full[:512])          # warm LAPACK threads
     xs, ys = synth_expert(n_small, d, 1234)
     ts = []
@@ -80,19 +117,28 @@ def cpu_baseline(x_full, y_full, hp, n_small, gpu_loss, gpu_grad, full_size):
     scale = (n_full / n_small) ** 3
     out = {
         "unit": "evals/s", "cores": cores, "kind": "port",
+        "threads": {"used": cores, "torch_default": threads_default, "host": share,
+                    "rule": "min(affinity mask, cgroup CPU quota, physical cores); PG_BENCH_CPU_THREADS overrides"},
+        "loadavg_before": list(load0) if load0 else None,
         "small_sample": {"n": n_small, "seconds_min_of_2": t_small, "seconds_all": ts,
                          "extrapolated_evals_per_s_at_full_n": 1.0 / (t_small * scale)},
     }
     if full_size:
-        t0 = time.perf_counter()
-        l_ref, g_ref = orc.mle_loss_and_grad_lean(hp, x_full, y_full)
-        t_full = time.perf_counter() - t0
+        t_all = []
+        for rep in range(2):
+            t0 = time.perf_counter()
+            l_ref, g_ref = orc.mle_loss_and_grad_lean(hp, x_full, y_full)
+            t_all.append(time.perf_counter() - t0)
+            if t_all[-1] > 75.0:          # keep the default run within a few minutes on a slow or loaded host
+                break
+        t_full = min(t_all)
         out["value"] = 1.0 / t_full
         out["seconds_measured"] = t_full
-        out["sample"] = ("ONE measured lean K^-1-route NLML+grad evaluation at the full N=%d D=%d on the GPU's own data "
-                         "(oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK potrf + potri, %d intra-op threads): %.1f s; "
+        out["seconds_all"] = t_all
+        out["sample"] = ("min of %d measured lean K^-1-route NLML+grad evaluations at the full N=%d D=%d on the GPU's own data "
+                         "(oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK potrf + potri, %d intra-op threads): %s s; "
                          "beside it min of 2 at N=%d: %.2f s (x%.0f n^3-extrapolated: %.1f s)"
-                         % (n_full, d, cores, t_full, n_small, t_small, scale, t_small * scale))
+                         % (len(t_all), n_full, d, cores, " / ".join("%.1f" % t for t in t_all), n_small, t_small, scale, t_small * scale))
         out["parity_at_full_size"] = {
             "oracle_nlml": float(l_ref), "gpu_nlml": float(gpu_loss),
             "nlml_rel_err": abs(float(gpu_loss) - float(l_ref)) / abs(float(l_ref)),
@@ -107,6 +153,7 @@ def cpu_baseline(x_full, y_full, hp, n_small, gpu_loss, gpu_grad, full_size):
         out["sample"] = ("min of 2 lean K^-1-route NLML+grad evaluations (oracle.mle_loss_and_grad_lean: torch CPU fp64, LAPACK "
                          "potrf + potri, %d intra-op threads) at N=%d D=%d: %.2f s; n^3-scaled x%.0f to N=%d (extrapolated)"
                          % (cores, n_small, d, t_small, scale, n_full))
+    out["loadavg_after"] = list(os.getloadavg()) if hasattr(os, "getloadavg") else None
     return out
 
 
@@ -406,16 +453,22 @@ def main():
         # from separate rocprofv3 --pmc passes over the same evaluation (tools/probe_eval_once.py, tools/pmc_summary.py),
         # committed under profiles/ together with the identity of the build they were taken on.  A summary taken on
         # another build (kernel sources changed since) is not reported.
-        pmc_name = "r04_pmc_eval_traffic.json"
+        pmc_name = "r05_pmc_eval_traffic.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if n == 16384 and os.path.exists(pmc):
             with open(pmc) as fh:
                 js = json.load(fh)
             k = js["kernels"]["gemm_core"]
             if js.get("build", {}).get("src_sha16") == out["build"]["src_sha16"]:
-                out["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_unit"] = "B per launch (2 x FETCH_SIZE + WRITE_SIZE, %d launches, %.1f GB per evaluation)" % (
-                    k["launches"], k["hbm_bytes"] / 1e9)
+                # bytes per EVALUATION (the counter passes and the headline run different launch schedules, so a per-launch figure
+                # beside this object's `launches` would describe two different things: round-4 verdict)
+                out["roofline"]["traffic"] = k["hbm_bytes"]
+                out["roofline"]["traffic_unit"] = "B per evaluation (2 x FETCH_SIZE + WRITE_SIZE summed over the GEMM-core launches of one evaluation)"
+                out["roofline"]["traffic_schedule"] = {
+                    "launches": k["launches"], "bytes_per_launch": k["hbm_bytes_per_launch"],
+                    "note": "the counter passes run the classic chain without look-ahead (a counter-collecting profiler runs one kernel at a "
+                            "time: the coupled chain cannot run there); `launches` / `avg_launch_ms` of this object describe the single-stream "
+                            "profile mode of THIS run -- do not multiply across the two"}
                 out["roofline"]["traffic_source"] = "profiles/" + pmc_name
             else:
                 out["roofline"]["traffic_note"] = ("profiles/%s was taken on build %s, this is %s: not reported"
@@ -453,7 +506,7 @@ def main():
             return best
 
         # the covariance build: FOUR launches back to back between two events, so that the figure is the kernel's duration
-        # (what rocprofv3 --kernel-trace reports: profiles/r04_kernel_build_hbm.json) and not one launch's latency on top of it
+        # (what rocprofv3 --kernel-trace reports: profiles/r05_kernel_build_hbm.json) and not one launch's latency on top of it
         def build_x4(lower):
             for _ in range(4):
                 ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=lower, jitter=1e-7)
@@ -473,14 +526,14 @@ def main():
         out["roofline_kernel_build"]["lower_only"] = {"ms": t_lower, "algorithmic_bytes": bytes_lower,
                                                       "achieved": bytes_lower / t_lower / 1e6,
                                                       "frac": bytes_lower / t_lower / 1e6 / HBM_PEAK_GBS}
-        kbp = os.path.join(ROOT, "profiles", "r04_kernel_build_hbm.json")
+        kbp = os.path.join(ROOT, "profiles", "r05_kernel_build_hbm.json")
         if n == 16384 and os.path.exists(kbp):
             with open(kbp) as fh:
                 kj = json.load(fh)
             if kj.get("build", {}).get("src_sha16") == out["build"]["src_sha16"]:
                 out["roofline_kernel_build"]["traffic"] = kj["mirrored"]["hbm_bytes_pmc"]
                 out["roofline_kernel_build"]["lower_only"]["traffic"] = kj["lower_only"]["hbm_bytes_pmc"]
-                out["roofline_kernel_build"]["traffic_source"] = "profiles/r04_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
+                out["roofline_kernel_build"]["traffic_source"] = "profiles/r05_kernel_build_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled)"
         t_lower_single = timed(lambda: ops.kernel_build(spec, hpd, exp.x, None, a, lower_only=True, jitter=1e-7), 3)   # one launch, for the legs below
         out["roofline_kernel_build"]["lower_only"]["ms_single_launch"] = t_lower_single
 
@@ -579,7 +632,10 @@ def main():
                 "config": "pg.CG(pg.MLE(Exact_GP)).minimize(), maxiter = 50, N = %d D = %d, start hp sigma = 1 l = 1 sigma_n = 0.1" % (n, d),
                 "iterations": int(cg.res.nit), "evaluations": int(cg.res.nfev), "seconds": tcg, "ms_per_evaluation": 1e3 * tcg / max(int(cg.res.nfev), 1),
                 "evals_per_s": int(cg.res.nfev) / tcg, "nlml_start": nlml0, "nlml_end": nlml1, "scipy_success": bool(cg.res.success),
-                "note": "every evaluation is a full NLML + gradient (memo off); ms_per_evaluation includes scipy and the host round trip",
+                "note": "every evaluation is a full NLML + gradient (memo off); ms_per_evaluation includes scipy and the host round trip; "
+                        "scipy_success = false means scipy stopped at maxiter = 50 (status %d: %s), which the reference reports the same way -- it "
+                        "prints 'Optimizer Failed' and still writes res.x back (PyGPR/opt.py:61-65); the NLML decrease is asserted"
+                        % (int(getattr(cg.res, "status", -1)), str(getattr(cg.res, "message", ""))[:60]),
             }
             del gp3, mle3, cg
         finally:
@@ -761,6 +817,145 @@ def main():
         et["what"] = ("Exact_GP.update(), eager inverse: covariance build + Cholesky + L^-1 + alpha for nc experts of n points, best of 3; "
                       "batched = pg_build_potrf_trtri_batched + pg_alpha_batched (every launch covers all experts)")
         out["experts_together"] = et
+
+    # ---- the diagonal prediction experts-together (round 5): the reference predicts a batched model with ONE batched kernel / bmm /
+    # cholesky_solve (gpr.py:76-106 on x [nc, n, d]); rounds 1-4 walked the experts on the host.  (i) the reference's own test size
+    # (tests/test_gpr.py:59-100: ten experts of 100 points, m = 100) batched against the loop (PG_PREDICT_SERIAL=1), results asserted
+    # bit-identical; (ii) a committee of 64 experts of 1024 points (ng = 256 + 768 own), D = 16, 65 536 test points in batches of 8192.
+    if legs:
+        def predict_ms(gp_, xs_, serial, reps=5):
+            if serial:
+                os.environ["PG_PREDICT_SERIAL"] = "1"
+            try:
+                out_ = gp_.predict(xs_, var="diag")
+                torch.cuda.synchronize()
+                best = 1e30
+                for _ in range(reps):
+                    t0_ = time.perf_counter()
+                    out_ = gp_.predict(xs_, var="diag")
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0_)
+            finally:
+                os.environ.pop("PG_PREDICT_SERIAL", None)
+            return 1e3 * best, out_
+
+        rng_ = np.random.default_rng(3)
+        x_ = rng_.random((10, 100, 3)); y_ = np.sin(-x_.sum(-1)) + 0.1 * rng_.standard_normal((10, 100))
+        gp_ = pg.Exact_GP(torch.from_numpy(x_), torch.from_numpy(y_), cov)
+        gp_.set_params(torch.from_numpy(np.tile(np.concatenate([[1.0], np.full(3, 0.5), [0.1]]), (10, 1))))
+        xs_ = torch.from_numpy(rng_.random((100, 3))).cuda()
+        tb_, ob_ = predict_ms(gp_, xs_, False)
+        assert gp_.last_predict_batched
+        ts_, os_ = predict_ms(gp_, xs_, True)
+        assert not gp_.last_predict_batched and torch.equal(ob_[0], os_[0]) and torch.equal(ob_[1], os_[1])
+        out["predict_nc10_n100"] = {
+            "config": "Exact_GP.predict(var='diag') of a batched model: 10 experts x 100 points, D = 3, m = 100 test points (the reference's "
+                      "own test size, PyGPR/tests/test_gpr.py:59-100); factors resident",
+            "batched_ms": tb_, "one_after_the_other_ms": ts_, "speedup": ts_ / tb_, "bit_identical_to_the_loop": True,
+            "launches": "counted by rocprofv3: profiles/r05_predict_nc10_n100_kernel_stats.txt (tools/probe_predict_batched.py)",
+        }
+        del gp_
+        nc6, ng6, nls6, d6, m6, mb6 = 64, 256, 768, 16, 65536, 8192
+        xg6, yg6 = synth_expert(ng6, d6, 17)
+        sh6 = [synth_expert(nls6, d6, 300 + c) for c in range(nc6)]
+        g6 = pg.GRBCM(torch.from_numpy(np.stack([s_[0] for s_ in sh6])), torch.from_numpy(np.stack([s_[1] for s_ in sh6])),
+                      torch.from_numpy(xg6), torch.from_numpy(yg6), cov)
+        hp6 = torch.from_numpy(np.concatenate([[1.0], np.full(d6, 0.5), [0.1]]))
+        g6.gpg.set_params(hp6)
+        g6.set_local_params(hp6)
+        xs6 = torch.from_numpy(np.random.default_rng(4321).random((m6, d6))).cuda()
+
+        def committee_s(g_, xs__, mb_, serial):
+            if serial:
+                os.environ["PG_PREDICT_SERIAL"] = "1"
+            try:
+                g_.predict(xs__[:mb_])
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for s0_ in range(0, xs__.shape[0], mb_):
+                    mu_, var_ = g_.predict(xs__[s0_: s0_ + mb_])
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0_, mu_, var_
+            finally:
+                os.environ.pop("PG_PREDICT_SERIAL", None)
+
+        t6b, mu6b, var6b = committee_s(g6, xs6, mb6, False)
+        t6s, mu6s, var6s = committee_s(g6, xs6, mb6, True)
+        assert torch.equal(mu6b, mu6s) and torch.equal(var6b, var6s)
+        flop6 = float(m6) * (nc6 * float(ng6 + nls6) ** 2 + float(ng6) ** 2)
+        out["grbcm_predict_nc64_n1024"] = {
+            "value": m6 / t6b, "unit": "points/s", "seconds": t6b, "one_after_the_other_seconds": t6s, "speedup": t6s / t6b,
+            "config": "GRBCM.predict(var='diag'): %d experts x (%d global + %d own) points, D=%d, RBF+noise fp64, %d test points in batches of %d, "
+                      "one GPU; every expert's K* in one launch, means + variances in three, the committee's terms in one" % (nc6, ng6, nls6, d6, m6, mb6),
+            "bit_identical_to_the_loop": True, "mean_abs": float(mu6b.abs().mean()), "var_mean": float(var6b.mean()),
+            "roofline": {"bound": "mfma", "achieved": flop6 / t6b / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop6 / t6b / 1e12 / FP64_MATRIX_PEAK_TFLOPS, "algorithmic_flops": flop6,
+                         "kernel": "pg_gemm_kernel<double, NT, 128x128, column-sum epilogue> with the expert as second batch level",
+                         "note": "flop = m (nc n^2 + ng^2); per batch 4.3 GB of K* are written and read once (HBM-side: 8 nc n m B each way)"},
+        }
+        del g6, xs6, mu6b, mu6s, var6b, var6s
+        torch.cuda.empty_cache()
+
+    # ---- bound the 8-GPU efficiency on ONE GPU (round 5): the committee of config 4 built with k = 1, 2, 4 of its 8 local experts + the
+    # global expert -- what each rank owns at 8 / 4 / 2 GPUs -- beside the 8-expert run, the same 65 536 test points in batches of 8192.
+    # t_8 / (8 / k) / t_k is the strong-scaling efficiency that host overhead and per-batch fixed costs alone allow (no collective runs
+    # here: the all-reduce of a [3, m] + world batch is added from the last measured rehearsal, named in `allreduce_source`).
+    if legs and not args.no_grbcm:
+        nc, nls4, ng4, d4, m4, mb = 8, 8192, 1024, 16, 65536, 8192
+        xg4, yg4 = synth_expert(ng4, d4, 7)
+        sh = [synth_expert(nls4, d4, 100 + c) for c in range(nc)]
+        hp4 = torch.from_numpy(np.concatenate([[1.0], np.full(d4, 0.5), [0.1]]))
+        xs = torch.from_numpy(np.random.default_rng(4321).random((m4, d4))).cuda()
+        ar_us, ar_src = 0.0, None
+        for name_ in ("r05_bench_n2_gloo_rehearsal.json", "r04_bench_n2_gloo_rehearsal.json"):
+            pth = os.path.join(ROOT, "profiles", name_)
+            if os.path.exists(pth):
+                try:
+                    with open(pth) as fh:
+                        ar_us = float(json.load(fh)["grbcm_predict"]["allreduce_us_per_batch"])
+                    ar_src = "profiles/" + name_ + " (two gloo ranks on one GPU; RCCL over xGMI is unmeasured)"
+                    break
+                except Exception:
+                    pass
+        share = {}
+        for k_ in (8, 4, 2, 1):
+            gk = pg.GRBCM(torch.from_numpy(np.stack([s_[0] for s_ in sh[:k_]])), torch.from_numpy(np.stack([s_[1] for s_ in sh[:k_]])),
+                          torch.from_numpy(xg4), torch.from_numpy(yg4), cov)
+            gk.gpg.set_params(hp4)
+            gk.set_local_params(hp4)
+            gk.predict(xs[:mb])
+            torch.cuda.synchronize()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0_ = time.perf_counter()
+            e0_.record()
+            for s0_ in range(0, m4, mb):
+                gk.predict(xs[s0_: s0_ + mb])
+            e1_.record()
+            t_enq = time.perf_counter() - t0_          # host time to ENQUEUE all batches (nothing in predict() synchronises on one rank)
+            torch.cuda.synchronize()
+            t_k = time.perf_counter() - t0_
+            share[k_] = {"seconds": t_k, "ms_per_batch": 1e3 * t_k / (m4 // mb), "host_enqueue_ms_per_batch": 1e3 * t_enq / (m4 // mb),
+                         "gpu_ms_per_batch": e0_.elapsed_time(e1_) / (m4 // mb)}
+            del gk
+            torch.cuda.empty_cache()
+        nb_ = m4 // mb
+        proj = {}
+        for k_ in (4, 2, 1):
+            w_ = nc // k_
+            t_rank = share[k_]["seconds"] + nb_ * ar_us * 1e-6
+            proj["world_%d" % w_] = {"experts_per_rank": k_, "seconds_per_rank_projected": t_rank,
+                                     "efficiency_projected": share[8]["seconds"] / (w_ * t_rank),
+                                     "speedup_projected": share[8]["seconds"] / t_rank}
+        out["grbcm_predict_rank_share"] = {
+            "config": "config 4's committee (8 x (1024 + 8192) points, D = 16) built with k of its local experts + the global expert on ONE GPU; "
+                      "%d test points in batches of %d, diag variance" % (m4, mb),
+            "per_k": {str(k_): v_ for k_, v_ in share.items()}, "projection": proj,
+            "allreduce_us_per_batch_assumed": ar_us, "allreduce_source": ar_src,
+            "what": "efficiency_projected = t(8 experts) / (world x (t(k experts) + batches x all-reduce)): what per-batch fixed costs (the global "
+                    "expert's prediction, launches, aggregation, the one synchronising status read of the distributed path) allow; the "
+                    "north-star target is >= 6x at 8 GPUs (0.75)",
+        }
+        del xs
 
     # ---- BASELINE config 5: grBCM, 8 experts x (1024 + 32768) points, Matern-5/2, fp32, shared-hp co-training objective
     # sum_c NLML_c and its gradient (GRBCM_MLE): 1 warm-up + 3 evaluations.  At N = 1 the 8 experts run one after another

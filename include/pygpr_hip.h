@@ -68,6 +68,15 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
                     int nr, const void* Xc, long ldc, int nc, int d, int lower_only, int accumulate, double jitter,
                     void* K, long ldk, int rows_pad, int cols_pad, void* stream);
 
+/* The same for nexp experts of one shape in ONE launch (round 5; no accumulate pass): expert e builds K + e * k_stride from the row points
+ * Xr + e * xr_stride, the column points Xc + e * xc_stride and the hyper-parameters hp + e * hp_stride (strides in elements; 0 shares an
+ * operand).  Xc == NULL: symmetric builds on Xr (what pg_build_potrf_trtri_batched folds in).  A cross build with xr_stride = 0 is the
+ * reference's batched K* = cov.kernel(params [nc, nhp], x [nc, n, d], xp [m, d]) (gpr.py:79 on the batched x of gr_bcm.py:19-29), stored
+ * test-point-major; per expert the same kernel and numbers as pg_kernel_build. */
+int pg_kernel_build_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* Xr, long ldr,
+                            long xr_stride, int nr, const void* Xc, long ldc, long xc_stride, int nc, int d, int lower_only, double jitter,
+                            void* K, long ldk, long k_stride, int rows_pad, int cols_pad, int nexp, void* stream);
+
 /* dK[nhp][n][n] (contiguous, unpadded): the stack Covar.kernel_and_grad returns (covar.py:64-81,
  * 169-206, 247-269).  Drop-in surface only -- the NLML path never materialises it. */
 int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
@@ -212,6 +221,16 @@ int pg_predict_mean_q(pg_handle h, int dtype, int n_pad, int m_pad, const void* 
 int pg_predict_mean_q_kt(pg_handle h, int dtype, int n_pad, int m_pad, const void* Kt, long ldkt, const void* Minv,
                          long ldm, const void* alpha, void* mean, void* var, double kss, void* work, void* stream);
 
+/* The diagonal prediction of ALL experts of a batched model in three launches (round 5): what the reference does with one batched
+ * kernel / bmm / cholesky_solve on x [nc, n, d] (gpr.py:76-106; the committee's default, gr_bcm.py:151-155).  Expert e reads
+ * Kt + e * kt_stride, Minv + e * m_stride, alpha + e * alpha_stride and writes mean + e * mean_stride, var + e * var_stride (var == NULL:
+ * means only); kss_e = sum sigma_c^2 + sum sigma_n^2 is formed on the device from hp + e * hp_stride and spec.  work: (n_pad/64) * m_pad
+ * elements per expert at work_stride.  Per expert the numbers are those of pg_predict_mean_q_kt, bit for bit. */
+int pg_predict_mean_q_kt_batched(pg_handle h, int dtype, int n_pad, int m_pad, const void* Kt, long ldkt, long kt_stride, const void* Minv,
+                                 long ldm, long m_stride, const void* alpha, long alpha_stride, void* mean, long mean_stride, void* var,
+                                 long var_stride, const pg_covspec* spec, const double* hp, long hp_stride, void* work, long work_stride,
+                                 int nexp, void* stream);
+
 /* Dense product V = Minv Ks written out (needed for the full predictive covariance, gpr.py:108-120),
  * and C = C - V^T V on m_pad x m_pad (lower_only != 0: tiles on/below the diagonal only). */
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks,
@@ -236,6 +255,12 @@ int pg_syrk_nt_sub_batched(pg_handle h, int dtype, int m_pad, int n_pad, const v
 int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, const void* var_c, const void* var_g,
                          int is_first, int accumulate, double* out, long ldo, double* beta_out, double* prec_out,
                          void* stream);
+/* The same for the nexp experts a rank owns in ONE launch (round 5): expert c reads mean_l + c * mean_stride, var_l + c * var_stride and
+ * fills row c of beta_out / prec_out (leading dimension ldb); `first` = index of the committee's first expert among them (beta = 1), -1 if
+ * it lives on another rank.  The sums receive the experts' terms in order: bit-identical to nexp calls of pg_grbcm_local_terms. */
+int pg_grbcm_local_terms_batched(pg_handle h, int dtype, int m, const void* mean_l, long mean_stride, const void* var_l, long var_stride,
+                                 const void* var_g, int nexp, int first, int accumulate, double* out, long ldo, double* beta_out,
+                                 double* prec_out, long ldb, void* stream);
 /* Finish the committee (gr_bcm.py:133,143,144) from the summed terms and the global expert; beta0 / prec0
  * (nullable) receive the global expert's row of GRBCM.beta / GRBCM.prec. */
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g,

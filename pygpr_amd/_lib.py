@@ -37,6 +37,10 @@ _SIGS = {
     "pg_create": (_i, [C.POINTER(_vp)]),
     "pg_destroy": (_i, [_vp]),
     "pg_kernel_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _vp, _l, _i, _i, _i, _i, _d, _vp, _l, _i, _i, _vp]),
+    "pg_kernel_build_batched": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _l, _vp, _l, _l, _i, _vp, _l, _l, _i, _i, _i, _d, _vp, _l, _l, _i, _i, _i, _vp]),
+    "pg_predict_mean_q_kt_batched": (_i, [_vp, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, C.POINTER(CovSpec), _vp, _l, _vp, _l,
+                                          _i, _vp]),
+    "pg_grbcm_local_terms_batched": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _vp, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
     "pg_kernel_grad_build": (_i, [_vp, _i, C.POINTER(CovSpec), _vp, _vp, _l, _i, _i, _vp, _vp]),
     "pg_potrf_worksize": (_l, [_i, _i]),
     "pg_potrf": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _vp]),

@@ -93,6 +93,29 @@ class HipOps:
                 "pg_kernel_build")
         return out
 
+    def kernel_build_batched(self, spec, hp_all, xr, xc_all, out_all, lower_only=False, jitter=0.0):
+        """out_all[e] [rows_pad, cols_pad] <- k(xr_e, xc_e) for all experts in ONE launch (pg_kernel_build_batched): hp_all [nexp, nhp];
+        xr [m, d] (every expert at the same row points) or [nexp, m, d]; xc_all [nexp | 1, n, d] (one leading entry: shared points), or
+        None for symmetric builds on xr.  One pg_covspec only (no accumulate passes)."""
+        passes = _passes(spec)
+        assert len(passes) == 1
+        self._chk(hp_all, xr, xc_all, out_all)
+        assert hp_all.dtype == torch.float64 and out_all.dim() == 3
+        nexp = out_all.shape[0]
+        nr, d = xr.shape[-2], xr.shape[-1]
+        xr_stride = xr.stride(0) if (xr.dim() == 3 and xr.shape[0] > 1) else 0
+        if xc_all is not None:
+            nc = xc_all.shape[-2]
+            xc_stride = xc_all.stride(0) if (xc_all.dim() == 3 and xc_all.shape[0] > 1) else 0
+            ldc = xc_all.stride(-2)
+        else:
+            nc, xc_stride, ldc = nr, 0, 0
+        _lib.check(self.lib.pg_kernel_build_batched(
+            self.h, _code(out_all.dtype), C.byref(passes[0]), _p(hp_all), hp_all.stride(0) if hp_all.shape[0] > 1 else 0, _p(xr), xr.stride(-2),
+            xr_stride, nr, _p(xc_all), ldc, xc_stride, nc, d, int(lower_only), float(jitter), _p(out_all), out_all.stride(1),
+            out_all.stride(0), out_all.shape[1], out_all.shape[2], nexp, self._st()), "pg_kernel_build_batched")
+        return out_all
+
     def kernel_grad_build(self, spec, hp, x, out):
         """out[nhp, n, n] <- dK/dtheta stack (public Covar.kernel_and_grad only)."""
         self._chk(hp, x, out)
@@ -301,6 +324,24 @@ class HipOps:
                                                  _p(mean), _p(q), float(kss), _p(work), self._st()),
                    "pg_predict_mean_q_kt")
 
+    def predict_mean_q_kt_batched(self, kt_all, minv_all, alpha_all, mean_all, var_all, spec, hp_all, work_all):
+        """All experts' means (and diagonal variances, var_all not None) in three launches (pg_predict_mean_q_kt_batched): kt_all
+        [nexp, m_pad, n_pad], minv_all [nexp, n_pad, n_pad] (any common stride), alpha_all [nexp, n_pad], mean_all / var_all [nexp, m_pad],
+        hp_all [nexp | 1, nhp], work_all [nexp, (n_pad/64) m_pad].  kss is formed on the device from hp_all."""
+        passes = _passes(spec)
+        assert len(passes) == 1
+        self._chk(kt_all, alpha_all, mean_all, var_all, hp_all, work_all)
+        nexp, m_pad, n_pad = kt_all.shape
+        want_var = var_all is not None
+        if want_var:
+            assert minv_all.is_cuda and minv_all.stride(-1) == 1 and hp_all.dtype == torch.float64
+        _lib.check(self.lib.pg_predict_mean_q_kt_batched(
+            self.h, _code(kt_all.dtype), n_pad, m_pad, _p(kt_all), kt_all.stride(1), kt_all.stride(0),
+            _p(minv_all) if want_var else None, minv_all.stride(-2) if want_var else 0, minv_all.stride(0) if want_var else 0,
+            _p(alpha_all), alpha_all.stride(0), _p(mean_all), mean_all.stride(0), _p(var_all), var_all.stride(0) if want_var else 0,
+            C.byref(passes[0]), _p(hp_all), hp_all.stride(0) if hp_all.shape[0] > 1 else 0, _p(work_all), work_all.stride(0), nexp,
+            self._st()), "pg_predict_mean_q_kt_batched")
+
     def trmm_lower(self, minv, ks, v):
         self._chk(minv, ks, v)
         _lib.check(self.lib.pg_trmm_lower(self.h, _code(ks.dtype), ks.shape[0], ks.shape[1], _p(minv), minv.stride(0),
@@ -345,6 +386,20 @@ class HipOps:
         _lib.check(self.lib.pg_grbcm_local_terms(self.h, _code(mean_c.dtype), mean_c.numel(), _p(mean_c), _p(var_c),
                                                  _p(var_g), int(is_first), int(accumulate), _p(out), out.stride(0),
                                                  _p(beta), _p(prec), self._st()), "pg_grbcm_local_terms")
+
+    def grbcm_local_terms_batched(self, mean_all, var_all, var_g, first, accumulate, out, beta=None, prec=None):
+        """The terms of all owned experts in one launch: mean_all / var_all [nexp, >= m] (row stride arbitrary), out [3, m] float64,
+        beta / prec [nexp, m] float64 views (common row stride) or None; `first`: index of the committee's first expert among these, -1: none."""
+        self._chk(var_g, out)
+        assert out.dtype == torch.float64 and out.shape[0] == 3 and mean_all.stride(-1) == 1 and var_all.stride(-1) == 1
+        m = var_g.numel()
+        nexp = mean_all.shape[0]
+        if beta is not None:
+            assert beta.stride(-1) == 1 and prec.stride(-1) == 1 and (nexp == 1 or beta.stride(0) == prec.stride(0))
+        _lib.check(self.lib.pg_grbcm_local_terms_batched(
+            self.h, _code(mean_all.dtype), m, _p(mean_all), mean_all.stride(0), _p(var_all), var_all.stride(0), _p(var_g), nexp, int(first),
+            int(accumulate), _p(out), out.stride(0), _p(beta), _p(prec), beta.stride(0) if beta is not None else 0, self._st()),
+            "pg_grbcm_local_terms_batched")
 
     def grbcm_finish(self, sums, mean_g, var_g, mean, var, beta0=None, prec0=None):
         self._chk(sums, mean_g, var_g, mean, var, beta0, prec0)

@@ -371,6 +371,26 @@ int pg_kernel_build(pg_handle h, int dtype, const pg_covspec* spec, const double
                               lower_only, accumulate, jitter, (float*)K, ldk, rows_pad, cols_pad));
 }
 
+int pg_kernel_build_batched(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, long hp_stride, const void* Xr, long ldr,
+                            long xr_stride, int nr, const void* Xc, long ldc, long xc_stride, int nc, int d, int lower_only, double jitter,
+                            void* K, long ldk, long k_stride, int rows_pad, int cols_pad, int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && hp && Xr && K, "null pointer");
+    if (check_spec(spec, __func__, true)) return -1;
+    NEED(nexp >= 1 && nexp <= 65535, "1 <= nexp <= 65535");
+    const int sym = (Xc == nullptr);
+    if (sym) { Xc = Xr; ldc = ldr; nc = nr; xc_stride = xr_stride; }
+    NEED(nr >= 0 && nc >= 0 && rows_pad >= nr && cols_pad >= nc && ldk >= cols_pad, "inconsistent sizes");
+    NEED(!sym || rows_pad == cols_pad, "symmetric build needs a square padded shape");
+    NEED(nexp == 1 || k_stride >= (long)rows_pad * ldk, "experts' matrices overlap");
+    NEED(ldk % (dtype == PG_F64 ? 2 : 4) == 0, "ldk must keep rows 16-byte aligned");
+    DISPATCH(dtype,
+             pg_kbuild<double>(ST(stream), *spec, hp, (const double*)Xr, ldr, nr, (const double*)Xc, ldc, nc, d, sym, lower_only, 0, jitter,
+                               (double*)K, ldk, rows_pad, cols_pad, 0, 0, nexp, xc_stride, hp_stride, k_stride, xr_stride),
+             pg_kbuild<float>(ST(stream), *spec, hp, (const float*)Xr, ldr, nr, (const float*)Xc, ldc, nc, d, sym, lower_only, 0, jitter,
+                              (float*)K, ldk, rows_pad, cols_pad, 0, 0, nexp, xc_stride, hp_stride, k_stride, xr_stride));
+}
+
 int pg_kernel_grad_build(pg_handle h, int dtype, const pg_covspec* spec, const double* hp, const void* X, long ldx,
                          int n, int d, void* dK, void* stream) {
     JOIN(h, stream);
@@ -635,6 +655,28 @@ int pg_predict_mean_q_kt(pg_handle h, int dtype, int n_pad, int m_pad, const voi
                                            (const float*)alpha, (float*)mean, (float*)q, kss, (float*)work));
 }
 
+int pg_predict_mean_q_kt_batched(pg_handle h, int dtype, int n_pad, int m_pad, const void* Kt, long ldkt, long kt_stride, const void* Minv,
+                                 long ldm, long m_stride, const void* alpha, long alpha_stride, void* mean, long mean_stride, void* var,
+                                 long var_stride, const pg_covspec* spec, const double* hp, long hp_stride, void* work, long work_stride,
+                                 int nexp, void* stream) {
+    JOIN(h, stream);
+    NEED(h && Kt && alpha && mean && work, "null pointer");
+    NEED(!var || (Minv && hp), "variance needs Minv and hp");
+    if (var && check_spec(spec, __func__)) return -1;
+    NEED(nexp >= 1 && nexp <= 65535, "1 <= nexp <= 65535");
+    NEED(ldkt >= n_pad && (!Minv || ldm >= n_pad), "bad leading dimension");
+    NEED(nexp == 1 || (mean_stride >= m_pad && (!var || (var_stride >= m_pad && work_stride >= (long)(n_pad / 64) * m_pad))),
+         "experts' outputs / workspaces overlap");
+    static const pg_covspec none = {};
+    DISPATCH(dtype,
+             pg_predict_mean_q_kt_batched_t<double>(h, ST(stream), n_pad, m_pad, (const double*)Kt, ldkt, kt_stride, (const double*)Minv, ldm,
+                                                    m_stride, (const double*)alpha, alpha_stride, (double*)mean, mean_stride, (double*)var,
+                                                    var_stride, spec ? *spec : none, hp, hp_stride, (double*)work, work_stride, nexp),
+             pg_predict_mean_q_kt_batched_t<float>(h, ST(stream), n_pad, m_pad, (const float*)Kt, ldkt, kt_stride, (const float*)Minv, ldm,
+                                                   m_stride, (const float*)alpha, alpha_stride, (float*)mean, mean_stride, (float*)var,
+                                                   var_stride, spec ? *spec : none, hp, hp_stride, (float*)work, work_stride, nexp));
+}
+
 int pg_trmm_lower(pg_handle h, int dtype, int n_pad, int m_pad, const void* Minv, long ldm, const void* Ks, long ldks,
                   void* V, long ldv, void* stream) {
     JOIN(h, stream);
@@ -693,6 +735,19 @@ int pg_grbcm_local_terms(pg_handle h, int dtype, int m, const void* mean_c, cons
                                       is_first, accumulate, out, ldo, beta_out, prec_out),
              pg_grbcm_terms_t<float>(ST(stream), m, (const float*)mean_c, (const float*)var_c, (const float*)var_g,
                                      is_first, accumulate, out, ldo, beta_out, prec_out));
+}
+
+int pg_grbcm_local_terms_batched(pg_handle h, int dtype, int m, const void* mean_l, long mean_stride, const void* var_l, long var_stride,
+                                 const void* var_g, int nexp, int first, int accumulate, double* out, long ldo, double* beta_out,
+                                 double* prec_out, long ldb, void* stream) {
+    JOIN(h, stream);
+    NEED(h && mean_l && var_l && var_g && out, "null pointer");
+    NEED(ldo >= m && nexp >= 1 && (nexp == 1 || (!beta_out && !prec_out) || ldb >= m), "bad size");
+    DISPATCH(dtype,
+             pg_grbcm_terms_batched_t<double>(ST(stream), m, (const double*)mean_l, mean_stride, (const double*)var_l, var_stride,
+                                              (const double*)var_g, nexp, first, accumulate, out, ldo, beta_out, prec_out, ldb),
+             pg_grbcm_terms_batched_t<float>(ST(stream), m, (const float*)mean_l, mean_stride, (const float*)var_l, var_stride,
+                                             (const float*)var_g, nexp, first, accumulate, out, ldo, beta_out, prec_out, ldb));
 }
 
 int pg_grbcm_finish(pg_handle h, int dtype, int m, const double* sums, long lds, const void* mean_g, const void* var_g,

@@ -306,7 +306,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP<T>& p, int ti, int tj, cha
             s += __shfl_xor(s, 32, 64);
             if (lane < 16) {
                 const int col = n0 + wn * WTN + j * 16 + lane;
-                p.part[(long)(m0 / 64 + wm) * p.ldp + col + zb * p.sC] = s;
+                p.part[(long)(m0 / 64 + wm) * p.ldp + col + zb * p.sC + (long)ze * p.eC] = s;   // (experts together: eC strides the partial sums)
             }
         }
     }
@@ -374,6 +374,7 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
         q.nexp = std::min(per, p.nexp - e0);
         q.A = p.A + (long)e0 * p.eA; q.B = p.B + (long)e0 * p.eB;
         if (p.C) q.C = p.C + (long)e0 * p.eC;
+        if (p.part) q.part = p.part + (long)e0 * p.eC;
         if (p.info) q.info = p.info + (long)e0 * p.einfo;
         dim3 grid((unsigned)tiles, (unsigned)(q.batch * q.nexp), 1);
         hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, q);

@@ -315,9 +315,10 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
                                                         const T* __restrict__ Xc, long ldc, int nc, int d,
                                                         int symmetric, int accumulate, double jitter,
                                                         T* __restrict__ K, long ldk, int ctile0, int ctile1, int presc, int S,
-                                                        long eX, long ehp, long eK) {
-    // batched experts (symmetric builds): blockIdx.y = expert, each with its own points, hyper-parameters and matrix
-    Xr += blockIdx.y * eX; Xc += blockIdx.y * eX; hp += blockIdx.y * ehp; K += blockIdx.y * eK;
+                                                        long eX, long ehp, long eK, long eXr) {
+    // batched experts: blockIdx.y = expert, each with its own points, hyper-parameters and matrix (cross builds: the row points --
+    // the test points of a prediction -- have their own stride, 0 when every expert predicts at the same points)
+    Xr += blockIdx.y * eXr; Xc += blockIdx.y * eX; hp += blockIdx.y * ehp; K += blockIdx.y * eK;
     int tr, tcs, ntile;
     kb_strip_of(blockIdx.x, symmetric, ctile0, ctile1, S, tr, tcs, ntile);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(256) void pg_kbuild_kernel(pg_covspec spec, const d
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
               const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,
-              long ldk, int rows_pad, int cols_pad, int col0, int col1, int nexp, long eX, long ehp, long eK) {
-    if (nexp > 1 && !symmetric) { pg_set_error("pg_kbuild: only symmetric builds are batched"); return -2; }
+              long ldk, int rows_pad, int cols_pad, int col0, int col1, int nexp, long eX, long ehp, long eK, long eXr) {
+    if (eXr < 0 || symmetric) eXr = eX;      // symmetric builds: one point set per expert
     if (rows_pad % KT || cols_pad % KT || d < 1 || d > PG_MAX_DIM) {
         pg_set_error("pg_kbuild: bad shape rows_pad=%d cols_pad=%d d=%d", rows_pad, cols_pad, d);
         return -2;
@@ -488,7 +489,7 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
     const int npf = d <= 8 ? 2 : (d <= 16 ? 4 : 16);
 #define KB_LAUNCH(M, P, F)                                                                                                           \
     hipLaunchKernelGGL((pg_kbuild_kernel<T, M, P, F>), dim3((unsigned)strips, (unsigned)nexp), dim3(256), lds, st, spec, hp, Xr, ldr, nr, Xc, \
-                       ldc, nc, d, symmetric, accumulate, jitter, K, ldk, c0, c1, presc, S, eX, ehp, eK)
+                       ldc, nc, d, symmetric, accumulate, jitter, K, ldk, c0, c1, presc, S, eX, ehp, eK, eXr)
     bool launched = false;
     if constexpr (sizeof(T) == 8) {
         if (presc == 2) {
@@ -515,9 +516,9 @@ int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T*
     return 0;
 }
 template int pg_kbuild<double>(hipStream_t, const pg_covspec&, const double*, const double*, long, int,
-                               const double*, long, int, int, int, int, int, double, double*, long, int, int, int, int, int, long, long, long);
+                               const double*, long, int, int, int, int, int, double, double*, long, int, int, int, int, int, long, long, long, long);
 template int pg_kbuild<float>(hipStream_t, const pg_covspec&, const double*, const float*, long, int,
-                              const float*, long, int, int, int, int, int, double, float*, long, int, int, int, int, int, long, long, long);
+                              const float*, long, int, int, int, int, int, double, float*, long, int, int, int, int, int, long, long, long, long);
 
 // ------------------------------------------------------------------------------------------------
 // dK stack of the public Covar.kernel_and_grad (covar.py:64-81,169-206,247-269): dK[p][i][j] for

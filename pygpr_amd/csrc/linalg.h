@@ -48,6 +48,13 @@ int pg_predict_mean_q_t(pg_ctx*, hipStream_t, int n, int m, const T* Ks, long ld
 template <typename T>
 int pg_predict_mean_q_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* Kt, long ldkt, const T* M, long ldm, const T* alpha,
                         T* mean, T* q, double kss, T* work);
+template <typename T>
+int pg_predict_mean_q_kt_batched_t(pg_ctx*, hipStream_t, int n, int m, const T* Kt, long ldkt, long ekt, const T* M, long ldm, long em,
+                                   const T* alpha, long ea, T* mean, long emean, T* q, long evar, const pg_covspec& spec, const double* hp,
+                                   long ehp, T* work, long ew, int nexp);
+template <typename T>
+int pg_grbcm_terms_batched_t(hipStream_t, int m, const T* mean_l, long emean, const T* var_l, long evar, const T* var_g, int nexp, int first,
+                             int accumulate, double* out, long ldo, double* beta_out, double* prec_out, long ldb);
 template <typename T> int pg_trmm_lower_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, const T* Ks, long ldks, T* V, long ldv);
 template <typename T> int pg_syrk_tn_sub_t(pg_ctx*, hipStream_t, int m, int n, const T* V, long ldv, T* C, long ldc, int lower_only);
 template <typename T> int pg_trmm_lower_kt_t(pg_ctx*, hipStream_t, int n, int m, const T* M, long ldm, long em, const T* Kt, long ldkt, long ekt, T* Vt,

@@ -293,20 +293,30 @@ __global__ __launch_bounds__(256) void nlml_finish_kernel(const T* __restrict__ 
     if (tid == 0) out[0] = red[0] + red[1] + red[2] + red[3] + 0.5 * logdet[0] + 0.5 * (double)n * 1.83787706640934548356;
 }
 
+// Per-expert grBCM terms (gr_bcm.py:125-144) for nexp owned experts in one launch (round 5; the one-expert entry point is the same kernel
+// with nexp = 1): out[0..2][j] (+)= sum_c beta_c, beta_c prec_c, beta_c prec_c mean_c with beta_c = 1/2 (log prec_c - log prec_g), or 1 for
+// the committee's first expert (c == first; gr_bcm.py:132).  Thread j walks the experts in order, so the sums receive the terms in the
+// order of one-by-one calls (bit-identical); rows c of beta_out / prec_out (leading dimension ldb) receive expert c's.
 template <typename T>
-__global__ __launch_bounds__(256) void grbcm_terms_kernel(const T* __restrict__ mean_c, const T* __restrict__ var_c,
-                                                          const T* __restrict__ var_g, int m, int is_first,
-                                                          int accumulate, double* __restrict__ out, long ldo,
-                                                          double* __restrict__ beta_out, double* __restrict__ prec_out) {
+__global__ __launch_bounds__(256) void grbcm_terms_batched_kernel(const T* __restrict__ mean_l, long emean, const T* __restrict__ var_l, long evar,
+                                                                  const T* __restrict__ var_g, int m, int nexp, int first, int accumulate,
+                                                                  double* __restrict__ out, long ldo, double* __restrict__ beta_out,
+                                                                  double* __restrict__ prec_out, long ldb) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
-    const double pc = 1.0 / (double)var_c[j], pg = 1.0 / (double)var_g[j];
-    const double beta = is_first ? 1.0 : 0.5 * (log(pc) - log(pg));
-    if (beta_out) beta_out[j] = beta;
-    if (prec_out) prec_out[j] = pc;
-    const double t0 = beta, t1 = beta * pc, t2 = beta * pc * (double)mean_c[j];
-    if (accumulate) { out[j] += t0; out[ldo + j] += t1; out[2 * ldo + j] += t2; }
-    else { out[j] = t0; out[ldo + j] = t1; out[2 * ldo + j] = t2; }
+    const double pg = 1.0 / (double)var_g[j];
+    const double lpg = log(pg);
+    double s0 = accumulate ? out[j] : 0.0, s1 = accumulate ? out[ldo + j] : 0.0, s2 = accumulate ? out[2 * ldo + j] : 0.0;
+    for (int c = 0; c < nexp; ++c) {
+        const double pc = 1.0 / (double)var_l[c * evar + j];
+        const double beta = (c == first) ? 1.0 : 0.5 * (log(pc) - lpg);
+        if (beta_out) beta_out[c * ldb + j] = beta;
+        if (prec_out) prec_out[c * ldb + j] = pc;
+        const double t1 = beta * pc;
+        if (c == 0 && !accumulate) { s0 = beta; s1 = t1; s2 = t1 * (double)mean_l[c * emean + j]; }
+        else { s0 += beta; s1 += t1; s2 += t1 * (double)mean_l[c * emean + j]; }
+    }
+    out[j] = s0; out[ldo + j] = s1; out[2 * ldo + j] = s2;
 }
 
 template <typename T>
@@ -1095,7 +1105,8 @@ int pg_alpha_nlml_async_t(pg_ctx* ctx, hipStream_t st, int n_real, int n, const 
 // y[j] = sum_i A[j][i] x[i] for a row-major A [m x n]: one wave per row, 16-byte loads (n a multiple of 256)
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ A, long lda, int n, const T* __restrict__ x,
-                                                        T* __restrict__ y) {
+                                                        T* __restrict__ y, long eA = 0, long ex = 0, long ey = 0) {
+    A += blockIdx.y * eA; x += blockIdx.y * ex; y += blockIdx.y * ey;         // batched experts
     constexpr int VE = 16 / sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VE)));
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1127,6 +1138,49 @@ int pg_predict_mean_q_kt_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* K
         int rc = pg_gemm<T>(ctx, st, GEMM_NT_128_SS, p);
         if (rc) return rc;
         hipLaunchKernelGGL(colreduce_kernel<T>, dim3(m / 256), dim3(256), 0, st, work, (long)m, n / 64, m, q, 0, kss, -1.0, 0);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// var_e[j] = kss_e - sum_rc part_e[rc][j] with kss_e = sum sigma_c^2 + sum sigma_n^2 of expert e's hyper-parameters: the constant diagonal
+// of K** (gpr.py:98: White_noise sees xp = None), formed here so that the batched prediction needs no host arithmetic per expert.
+// (products and sums kept apart -- no FMA contraction -- so that the value is the one the host computes for the one-expert call)
+template <typename T>
+__global__ __launch_bounds__(256) void predict_var_reduce_kernel(const T* __restrict__ part, long ldp, int nrc, int cols, T* __restrict__ out,
+                                                                 pg_covspec spec, const double* __restrict__ hp, long ehp, long ep, long eo) {
+    part += blockIdx.z * ep; out += blockIdx.z * eo; hp += blockIdx.z * ehp;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < spec.ncomp; ++c) s1 = __dadd_rn(s1, __dmul_rn(hp[spec.off[c]], hp[spec.off[c]]));
+    for (int c = 0; c < spec.nnoise; ++c) s2 = __dadd_rn(s2, __dmul_rn(hp[spec.noise_off[c]], hp[spec.noise_off[c]]));
+    const double kss = __dadd_rn(s1, s2);
+    double s = 0.0;
+    for (int rc = 0; rc < nrc; ++rc) s += (double)part[(long)rc * ldp + j];
+    out[j] = (T)(kss - s);
+}
+
+// The diagonal prediction of ALL experts of a batched model in three launches (round 5): the reference predicts a batched model with one
+// batched kernel / bmm / cholesky_solve (gpr.py:76-106 on x [nc, n, d]).  Expert e: Kt + e ekt (its test-point-major cross-covariance),
+// Minv + e em, alpha + e ea -> mean + e emean, var + e evar; work: (n/64) m elements per expert at stride ew.  The variance product is
+// the one-expert launch with the expert as the core's second batch level: per expert the same tiles in the same k order, bit for bit.
+template <typename T>
+int pg_predict_mean_q_kt_batched_t(pg_ctx* ctx, hipStream_t st, int n, int m, const T* Kt, long ldkt, long ekt, const T* M, long ldm, long em,
+                                   const T* alpha, long ea, T* mean, long emean, T* q, long evar, const pg_covspec& spec, const double* hp,
+                                   long ehp, T* work, long ew, int nexp) {
+    if (n % PG_PAD || m % 256 || n <= 0 || m <= 0) { pg_set_error("pg_predict_mean_q_kt_batched: n_pad=%d m_pad=%d must be multiples of 256", n, m); return -2; }
+    if (nexp < 1 || nexp > 65535) { pg_set_error("pg_predict_mean_q_kt_batched: 1 <= nexp <= 65535"); return -2; }
+    hipLaunchKernelGGL(gemv_rows_kernel<T>, dim3(m / 4, nexp), dim3(256), 0, st, Kt, ldkt, n, alpha, mean, ekt, ea, emean);
+    LAUNCH_CHECK();
+    if (q) {
+        GemmP<T> p = gp0<T>();
+        p.M = n; p.N = m; p.K = n; p.A = M; p.lda = ldm; p.B = Kt; p.ldb = ldkt; p.khi = 1;
+        p.part = work; p.ldp = m;
+        p.nexp = nexp; p.eA = em; p.eB = ekt; p.eC = ew;
+        int rc = pg_gemm<T>(ctx, st, GEMM_NT_128_SS, p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(predict_var_reduce_kernel<T>, dim3(m / 256, 1, nexp), dim3(256), 0, st, (const T*)work, (long)m, n / 64, m, q, spec, hp, ehp, ew, evar);
         LAUNCH_CHECK();
     }
     return 0;
@@ -1208,8 +1262,16 @@ int pg_syrk_tn_sub_t(pg_ctx* ctx, hipStream_t st, int m, int n, const T* V, long
 template <typename T>
 int pg_grbcm_terms_t(hipStream_t st, int m, const T* mean_c, const T* var_c, const T* var_g, int is_first, int accumulate,
                      double* out, long ldo, double* beta_out, double* prec_out) {
-    hipLaunchKernelGGL(grbcm_terms_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, mean_c, var_c, var_g, m, is_first,
-                       accumulate, out, ldo, beta_out, prec_out);
+    hipLaunchKernelGGL(grbcm_terms_batched_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, mean_c, 0L, var_c, 0L, var_g, m, 1, is_first ? 0 : -1,
+                       accumulate, out, ldo, beta_out, prec_out, 0L);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int pg_grbcm_terms_batched_t(hipStream_t st, int m, const T* mean_l, long emean, const T* var_l, long evar, const T* var_g, int nexp, int first,
+                             int accumulate, double* out, long ldo, double* beta_out, double* prec_out, long ldb) {
+    hipLaunchKernelGGL(grbcm_terms_batched_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, st, mean_l, emean, var_l, evar, var_g, m, nexp, first,
+                       accumulate, out, ldo, beta_out, prec_out, ldb);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1263,6 +1325,10 @@ template <typename T> int pg_tril_t(hipStream_t st, int n, T* A, long lda) {
                                         T*, double, T*);                                                               \
     template int pg_predict_mean_q_kt_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, const T*, T*, \
                                            T*, double, T*);                                                            \
+    template int pg_predict_mean_q_kt_batched_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, long, const T*, long, long, const T*, long, T*, long, \
+                                                   T*, long, const pg_covspec&, const double*, long, T*, long, int);   \
+    template int pg_grbcm_terms_batched_t<T>(hipStream_t, int, const T*, long, const T*, long, const T*, int, int, int, double*, long, double*, \
+                                             double*, long);                                                           \
     template int pg_trmm_lower_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, const T*, long, T*, long);         \
     template int pg_syrk_tn_sub_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, T*, long, int);                     \
     template int pg_trmm_lower_kt_t<T>(pg_ctx*, hipStream_t, int, int, const T*, long, long, const T*, long, long, T*, long, long, int); \

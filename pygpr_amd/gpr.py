@@ -4,8 +4,9 @@
 `predict` = K* build, mean K* alpha, and either the diagonal predictive variance
 diag(K**) - rowsum(K* o (K^-1 K*^T)^T) (gpr.py:96-106) or the full covariance (gpr.py:108-120).
 All state lives on the GPU in padded buffers (n rounded up to 256, identity in the padding); the
-leading expert dimension of the reference's batched models lives in stacked tensors (`_batch`): factorisation, inverse and
-weights of all experts are one batched call; prediction walks the experts.
+leading expert dimension of the reference's batched models lives in stacked tensors (`_batch`): factorisation, inverse,
+weights AND the prediction of all experts are batched calls (round 5: K* of every expert in one launch, mean + diagonal
+variance in three, gpr.py:76-106 on x [nc, n, d]; PG_PREDICT_SERIAL=1 walks the experts one by one as rounds 1-4 did).
 
 Differences a caller can observe:
   * the triangular solves against K* use the explicit inverse factor L^-1 (cached per update), so the
@@ -28,7 +29,8 @@ _CHUNK = 8192  # test points per device batch
 # up to this padded size; above it the per-step launches no longer matter and each expert takes the single-model schedule with
 # its flag-coupled chain, one after the other.  PG_BATCH_MAX_N overrides (0: never batch).
 _BATCH_MAX_N = int(os.environ.get("PG_BATCH_MAX_N", "12288"))
-_FULL_VT_BYTES = 16 << 30   # predict(var="full"): experts whose V^T fit this together share one rank-n update launch
+_FULL_VT_BYTES = 16 << 30   # predict(var="full"): experts whose V^T fit this together share one rank-n update launch (and at most
+                            # 40 % of the device memory that is free when the call starts: `_group_budget`)
 _BATCH_EAGER_N = 4096   # batched experts up to this size form L^-1 with the factor even when nobody asked for variances: the
                         # batched inverse + three batched mat-vec launches are cheaper than one substitution sweep per expert
 
@@ -64,6 +66,36 @@ def _checked(enqueue, infos):
         enqueue()
         vals = [int(v) for v in infos()]
     return vals
+
+
+def _group_budget(cap):
+    """Bytes a prediction may spend on the per-expert scratch of ONE launch group: `cap`, but never more than 40 % of what the device
+    has free right now (torch's cached blocks count as free: they are re-used) -- a fuller or smaller device gets smaller groups,
+    down to one expert per launch, instead of an out-of-memory error."""
+    try:
+        free, _ = torch.cuda.mem_get_info()
+        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+    except Exception:
+        return cap
+    return max(1, min(cap, int(0.4 * free)))
+
+
+def _stacked_rows(ts):
+    """ts: per-expert 1-D device tensors.  If they are rows of one buffer at a constant stride, that buffer as a [len(ts), m] view;
+    None otherwise (the committee's batched aggregation kernel takes a base pointer and a stride)."""
+    if not ts:
+        return None
+    t0 = ts[0]
+    if any(t.dim() != 1 or t.stride(0) != 1 or t.dtype != t0.dtype or t.numel() != t0.numel() for t in ts):
+        return None
+    base = t0.untyped_storage().data_ptr()
+    if any(t.untyped_storage().data_ptr() != base for t in ts):      # views of ONE allocation only
+        return None
+    item = t0.element_size()
+    step = (ts[1].data_ptr() - t0.data_ptr()) // item if len(ts) > 1 else t0.numel()
+    if len(ts) > 1 and (step < t0.numel() or any(t.data_ptr() - t0.data_ptr() != i * step * item for i, t in enumerate(ts))):
+        return None
+    return torch.as_strided(t0, (len(ts), t0.numel()), (step, 1))
 
 
 class GPR:
@@ -350,9 +382,10 @@ class Exact_GP(GPR):
         return mean, None
 
     def _predict_full(self, xqs):
-        """K** - K* K^-1 K*^T = K** - V^T V with V = L^-1 K*^T (gpr.py:108-120) for every expert (expert b at the points xqs[b]): per
-        expert the test-point-major K*, Vt = K* L^-T (both operands read along k) and K**; then ONE rank-n update for all experts
-        -- the 136 lower tiles of one 2048 x 2048 output leave three quarters of the chip idle, eight experts' tiles fill it."""
+        """Mean K* alpha and K** - K* K^-1 K*^T = K** - V^T V with V = L^-1 K*^T (gpr.py:80-85,108-120) for every expert (expert b at the
+        points xqs[b]): per expert the test-point-major K* -- built ONCE, the mean is taken from it too (round 4 built it a second time
+        for the mean) --, Vt = K* L^-T (both operands read along k) and K**; then ONE rank-n update for all experts -- the 136 lower tiles
+        of one 2048 x 2048 output leave three quarters of the chip idle, eight experts' tiles fill it.  Returns (means, covariances)."""
         ops = get_ops()
         spec, _ = spec_of(self.cov, self._x.shape[-1])
         experts = self._experts
@@ -360,12 +393,15 @@ class Exact_GP(GPR):
         m_pad = pad_to(m)
         item = torch.empty(0, dtype=self.dtype).element_size()
         c_all = ops.empty(len(experts), m_pad, m_pad, dtype=self.dtype)
+        mean_all = ops.empty(len(experts), m_pad, dtype=self.dtype)
+        dummy = ops.empty(256, dtype=self.dtype)
+        budget = _group_budget(_FULL_VT_BYTES)      # per group: Vt and (stacked inverses) K* of every expert in it
         b = 0
         while b < len(experts):
             n_pad = experts[b].n_pad
-            # experts of one padded size share a launch, within 16 GB of Vt
+            # experts of one padded size share a launch, within the budget (never fewer than one)
             cnt = 1
-            while (b + cnt < len(experts) and experts[b + cnt].n_pad == n_pad and (cnt + 1) * m_pad * n_pad * item <= _FULL_VT_BYTES):
+            while (b + cnt < len(experts) and experts[b + cnt].n_pad == n_pad and 2 * (cnt + 1) * m_pad * n_pad * item <= budget):
                 cnt += 1
             vt = ops.empty(cnt, m_pad, n_pad, dtype=self.dtype)
             minvs = [self._minv(experts[b + i]) for i in range(cnt)]
@@ -376,6 +412,7 @@ class Exact_GP(GPR):
             for i in range(cnt):
                 e = experts[b + i]
                 ops.kernel_build(spec, e.hp, xqs[b + i], e.x, kt[i if stacked else 0])
+                ops.predict_mean_q_kt(kt[i if stacked else 0], None, e.alpha, mean_all[b + i], None, 0.0, dummy)   # mean = K* alpha
                 if not stacked:
                     ops.trmm_lower_kt(minvs[i], kt[0], vt[i])
                 ops.kernel_build(spec, e.hp, xqs[b + i], None, c_all[b + i])   # K** incl. sigma_n^2, padding = identity
@@ -387,7 +424,54 @@ class Exact_GP(GPR):
         for i in range(len(experts)):
             ops.symmetrize(c_all[i], m_pad)                 # the upper triangle is the mirror: exactly symmetric
             out.append(c_all[i][:m, :m])
-        return out
+        return [mean_all[i, :m] for i in range(len(experts))], out
+
+    def _predict_batched(self, xpd, want):
+        """Mean (and diagonal variance) of ALL experts of a model whose experts live in stacked buffers (`_batch`): per chunk of test
+        points ONE launch builds every expert's test-point-major K*, three more give every mean and variance (round 5; the reference:
+        one batched kernel / bmm / cholesky_solve, gpr.py:76-106).  Per expert the numbers are those of `_predict_expert`, bit for bit."""
+        ops = get_ops()
+        spec, _ = spec_of(self.cov, self._x.shape[-1])
+        bat, experts = self._bat, self._experts
+        nb, n_pad = len(experts), experts[0].n_pad
+        m = xpd.shape[-2]
+        diag = want == "diag"
+        if diag and bat["minv"] is None:      # inverses not formed with the factor (lazy model): form them into one stack now
+            bat["minv"] = ops.empty(nb, n_pad, n_pad, dtype=self.dtype)
+            for b, e in enumerate(experts):
+                e.minv, e.minv_valid = bat["minv"][b], False
+        if diag:
+            for e in experts:
+                self._minv(e)
+        mean_all = ops.empty(nb, m, dtype=self.dtype)
+        var_all = ops.empty(nb, m, dtype=self.dtype) if diag else None
+        item = torch.empty(0, dtype=self.dtype).element_size()
+        x_all = self._x_all
+        for s in range(0, m, _CHUNK):
+            xq = xpd[..., s: s + _CHUNK, :]
+            xq = xq if xq.is_contiguous() else xq.contiguous()
+            mc = xq.shape[-2]
+            m_pad = pad_to(mc)
+            # experts per launch group: every expert's K* (m_pad x n_pad) at once, within the memory budget
+            per = m_pad * n_pad * item
+            grp = max(1, min(nb, _group_budget(64 << 30) // per))
+            key = ("bat", grp, m_pad, n_pad, diag)
+            if self._pbuf is None or self._pbuf[0] != key:
+                self._pbuf = None
+                self._pbuf = (key, ops.empty(grp, m_pad, n_pad, dtype=self.dtype), ops.empty(grp, (n_pad // 64) * m_pad, dtype=self.dtype),
+                              ops.empty(grp, m_pad, dtype=self.dtype), ops.empty(grp, m_pad, dtype=self.dtype) if diag else None)
+            _, kt, work, mu, vq = self._pbuf
+            for b0 in range(0, nb, grp):
+                cnt = min(grp, nb - b0)
+                xr = xq if xq.dim() == 2 else (xq[b0: b0 + cnt] if xq.shape[0] > 1 else xq[0])
+                xc = x_all[b0: b0 + cnt] if x_all.shape[0] > 1 else x_all
+                ops.kernel_build_batched(spec, bat["hp"][b0: b0 + cnt], xr, xc, kt[:cnt])
+                ops.predict_mean_q_kt_batched(kt[:cnt], bat["minv"][b0: b0 + cnt] if diag else None, bat["alpha"][b0: b0 + cnt], mu[:cnt],
+                                              vq[:cnt] if diag else None, spec, bat["hp"][b0: b0 + cnt], work[:cnt])
+                mean_all[b0: b0 + cnt, s: s + mc] = mu[:cnt, :mc]
+                if diag:
+                    var_all[b0: b0 + cnt, s: s + mc] = vq[:cnt, :mc]
+        return [mean_all[b] for b in range(nb)], ([var_all[b] for b in range(nb)] if diag else [None] * nb)
 
     def _predict_device(self, xpd, want):
         """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points: xpd [m, d]
@@ -397,15 +481,18 @@ class Exact_GP(GPR):
         self.update()
         if xpd.dim() == 3 and xpd.shape[0] not in (1, len(self._experts)):
             raise RuntimeError("batch dimension of xp (%d) does not match the %d experts" % (xpd.shape[0], len(self._experts)))
-        means, covs, xqs = [], [], []
+        if want == "full":       # K* is built once per expert there: mean, Vt and the update all come from it
+            return self._predict_full([xpd if xpd.dim() == 2 else xpd[b % xpd.shape[0]] for b in range(len(self._experts))])
+        if self._bat is not None and len(self._experts) > 1 and not os.environ.get("PG_PREDICT_SERIAL"):
+            self.last_predict_batched = True
+            return self._predict_batched(xpd, want)
+        self.last_predict_batched = False
+        means, covs = [], []
         for b, e in enumerate(self._experts):
             xq = xpd if xpd.dim() == 2 else xpd[b % xpd.shape[0]]
             mu, cv = self._predict_expert(b, e, xq, want)
             means.append(mu)
             covs.append(cv)
-            xqs.append(xq)
-        if want == "full":
-            covs = self._predict_full(xqs)
         return means, covs
 
     def predict(self, xp: Tensor, var: str = "full") -> Sequence[Tensor]:

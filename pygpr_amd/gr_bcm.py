@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from ._ops import get_ops, pad_to
-from .gpr import GPR, Exact_GP, _checked, _lin_alg_error
+from .gpr import GPR, Exact_GP, _checked, _lin_alg_error, _stacked_rows
 from .loss import MLE, Loss
 
 # aggregate_full_covar: the owned experts' m x m covariances are inverted in ONE batched call per step up to this padded size
@@ -149,9 +149,15 @@ class GRBCM(GPR):
         sums = flat[: 3 * m].view(3, m)
         beta = ops.empty(nloc + 1, m, dtype=torch.float64)
         prec = ops.empty(nloc + 1, m, dtype=torch.float64)
-        for c in range(nloc):
-            ops.grbcm_local_terms(means_l[c], vars_l[c], var_g, (self.lo + c) == 0, True, sums,
-                                  beta[c + 1], prec[c + 1])
+        # all owned experts' terms in ONE launch when their means / variances are rows of one buffer (the batched prediction's
+        # outputs): the kernel walks the experts in order, so the sums are those of the one-by-one calls bit for bit
+        ms, vs = (_stacked_rows(means_l), _stacked_rows(vars_l)) if nloc > 1 and not os.environ.get("PG_PREDICT_SERIAL") else (None, None)
+        if ms is not None and vs is not None:
+            ops.grbcm_local_terms_batched(ms, vs, var_g, 0 if self.lo == 0 else -1, True, sums, beta[1:], prec[1:])
+        else:
+            for c in range(nloc):
+                ops.grbcm_local_terms(means_l[c], vars_l[c], var_g, (self.lo + c) == 0, True, sums,
+                                      beta[c + 1], prec[c + 1])
         if self.distributed:
             self._reduce_terms(flat, m)
         mean, var = ops.empty(m, dtype=mean_g.dtype), ops.empty(m, dtype=mean_g.dtype)

@@ -74,6 +74,13 @@ class OracleOps:
             o[: x.shape[0], : xq.shape[0]] = _k(comps, x, xq)
         return out
 
+    def kernel_build_batched(self, spec, hp_all, xr, xc_all, out_all, lower_only=False, jitter=0.0):
+        for e in range(out_all.shape[0]):
+            xr_e = xr if xr.dim() == 2 else xr[e % xr.shape[0]]
+            xc_e = None if xc_all is None else (xc_all if xc_all.dim() == 2 else xc_all[e % xc_all.shape[0]])
+            self.kernel_build(spec, hp_all[e % hp_all.shape[0]], xr_e, xc_e, out_all[e], lower_only, jitter)
+        return out_all
+
     def kernel_grad_build(self, spec, hp, x, out):
         h, xx = _np(hp), _np(x).astype(np.float64)
         d = xx.shape[1]
@@ -209,6 +216,15 @@ class OracleOps:
     def predict_mean_q_kt(self, kt, minv, alpha, mean, var, kss, work):
         self.predict_mean_q(torch.from_numpy(np.ascontiguousarray(_np(kt).T)), minv, alpha, mean, var, kss, work)
 
+    def predict_mean_q_kt_batched(self, kt_all, minv_all, alpha_all, mean_all, var_all, spec, hp_all, work_all):
+        for e in range(kt_all.shape[0]):
+            h = _np(hp_all[e % hp_all.shape[0]])
+            kss = 0.0
+            for sp in _passes(spec):
+                kss += sum(h[sp.off[c]] ** 2 for c in range(sp.ncomp)) + sum(h[sp.noise_off[i]] ** 2 for i in range(sp.nnoise))
+            self.predict_mean_q_kt(kt_all[e], minv_all[e] if var_all is not None else None, alpha_all[e], mean_all[e],
+                                   var_all[e] if var_all is not None else None, kss, None)
+
     def trmm_lower(self, minv, ks, v):
         v.copy_(torch.from_numpy(np.tril(_np(minv).astype(np.float64)) @ _np(ks).astype(np.float64)))
 
@@ -239,6 +255,12 @@ class OracleOps:
             beta.copy_(torch.from_numpy(t[0]))
         if prec is not None:
             prec.copy_(torch.from_numpy(1.0 / _np(var_c).astype(np.float64)))
+
+    def grbcm_local_terms_batched(self, mean_all, var_all, var_g, first, accumulate, out, beta=None, prec=None):
+        m = var_g.numel()
+        for c in range(mean_all.shape[0]):
+            self.grbcm_local_terms(mean_all[c, :m], var_all[c, :m], var_g, c == first, accumulate or c > 0, out,
+                                   beta[c] if beta is not None else None, prec[c] if prec is not None else None)
 
     def grbcm_finish(self, sums, mean_g, var_g, mean, var, beta0=None, prec0=None):
         mu, v = orc.grbcm_finish(_np(sums), _np(mean_g).astype(np.float64), _np(var_g).astype(np.float64))

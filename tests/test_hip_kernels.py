@@ -1354,3 +1354,73 @@ def test_potrs_matrix_rhs_and_trsm(ops, n, nrhs):
     minv = ops.zeros(n, n)
     ops.trtri(ad, invd, minv)
     np.testing.assert_allclose(host(ops.potrs(None, None, bd, minv=minv)), x_ref, rtol=0, atol=1e-10 * np.abs(x_ref).max())
+
+
+def test_batched_prediction_entry_points_match_the_one_expert_calls(ops):
+    """pg_kernel_build_batched, pg_predict_mean_q_kt_batched, pg_grbcm_local_terms_batched (round 5): per expert the numbers of the
+    one-expert entry points BIT FOR BIT (same kernels, the expert is one more grid dimension) -- cross builds with shared and with
+    per-expert test points, shared and per-expert training points, means only and means + variances, fp64 and fp32."""
+    from pygpr_amd._ops import make_spec
+
+    rng = np.random.default_rng(21)
+    nexp, n, m, d = 3, 300, 200, 5
+    npad, mpad = 512, 256
+    spec = make_spec([0], [0], [d + 1])
+    for dtype in (torch.float64, torch.float32):
+        x = rng.random((nexp, n, d))
+        xp = rng.random((nexp, m, d))
+        hp = np.stack([np.concatenate([[1.0 + 0.1 * e], 0.5 + rng.random(d), [0.1 + 0.05 * e]]) for e in range(nexp)])
+        xd, xpd, hpd = dev(x, dtype), dev(xp, dtype), dev(hp)
+        for shared_xp in (True, False):
+            for shared_x in (False, True):
+                kt_all = ops.empty(nexp, mpad, npad, dtype=dtype)
+                xr = xpd[0] if shared_xp else xpd
+                xc = xd[:1] if shared_x else xd
+                ops.kernel_build_batched(spec, hpd, xr, xc, kt_all)
+                for e in range(nexp):
+                    kt = ops.empty(mpad, npad, dtype=dtype)
+                    ops.kernel_build(spec, hpd[e], xpd[0 if shared_xp else e], xd[0 if shared_x else e], kt)
+                    assert torch.equal(kt, kt_all[e]), (dtype, shared_xp, shared_x, e)
+        # symmetric batched build (lower-only with jitter) against the one-expert call
+        k_all = ops.zeros(nexp, npad, npad, dtype=dtype)
+        ops.kernel_build_batched(spec, hpd, xd, None, k_all, lower_only=True, jitter=1e-7)
+        for e in range(nexp):
+            k1 = ops.zeros(npad, npad, dtype=dtype)
+            ops.kernel_build(spec, hpd[e], xd[e], None, k1, lower_only=True, jitter=1e-7)
+            assert torch.equal(k1, k_all[e])
+        # factors, inverses, weights of the three experts (one-expert calls), then the batched prediction against the one-expert one
+        minv_all = ops.zeros(nexp, npad, npad, dtype=dtype)
+        alpha_all = ops.zeros(nexp, npad, dtype=dtype)
+        for e in range(nexp):
+            a = ops.empty(npad, npad, dtype=dtype)
+            invd = ops.potrf_workspace(npad, dtype)
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            ops.build_factor(spec, hpd[e], xd[e], a, invd, info, minv_all[e])
+            assert int(info.item()) == 0
+            alpha_all[e, :n] = dev(rng.standard_normal(n), dtype)
+        kt_all = ops.empty(nexp, mpad, npad, dtype=dtype)
+        ops.kernel_build_batched(spec, hpd, xpd, xd, kt_all)
+        work_all = ops.empty(nexp, (npad // 64) * mpad, dtype=dtype)
+        for want_var in (True, False):
+            mean_all, var_all = ops.empty(nexp, mpad, dtype=dtype), (ops.empty(nexp, mpad, dtype=dtype) if want_var else None)
+            ops.predict_mean_q_kt_batched(kt_all, minv_all if want_var else None, alpha_all, mean_all, var_all, spec, hpd, work_all)
+            for e in range(nexp):
+                mean1, var1 = ops.empty(mpad, dtype=dtype), (ops.empty(mpad, dtype=dtype) if want_var else None)
+                kss = float(hp[e, 0] ** 2 + hp[e, -1] ** 2)
+                ops.predict_mean_q_kt(kt_all[e], minv_all[e] if want_var else None, alpha_all[e], mean1, var1, kss, work_all[e])
+                assert torch.equal(mean1, mean_all[e])
+                if want_var:
+                    assert torch.equal(var1, var_all[e]), float((var1 - var_all[e]).abs().max())
+        # the committee's terms: all experts in one launch == one call per expert, accumulating
+        vg = dev(0.2 + rng.random(m), dtype)
+        mean_l, var_l = dev(rng.standard_normal((nexp, mpad)), dtype), dev(0.1 + rng.random((nexp, mpad)), dtype)
+        for first in (0, -1):
+            out_b, out_s = ops.zeros(3, m), ops.zeros(3, m)
+            beta_b, prec_b = ops.empty(nexp, m), ops.empty(nexp, m)
+            beta_s, prec_s = ops.empty(nexp, m), ops.empty(nexp, m)
+            ops.grbcm_local_terms_batched(mean_l, var_l, vg, first, True, out_b, beta_b, prec_b)
+            for e in range(nexp):
+                ops.grbcm_local_terms(mean_l[e, :m].contiguous(), var_l[e, :m].contiguous(), vg, e == first, True, out_s, beta_s[e], prec_s[e])
+            assert torch.equal(out_b, out_s) and torch.equal(beta_b, beta_s) and torch.equal(prec_b, prec_s)
+            ref = sum(orc.grbcm_terms(host(mean_l[e, :m]), host(var_l[e, :m]), host(vg), e == first) for e in range(nexp))
+            np.testing.assert_allclose(host(out_b), ref, rtol=1e-5 if dtype == torch.float32 else 1e-13)

@@ -841,3 +841,74 @@ def test_reference_test_sizes_batched(golden):
     np.testing.assert_allclose(N(var), r["sg_var"], rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(N(g.beta), r["sg_beta"], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(mu.numpy(), np.sin(r["sg_xl"][2].sum(-1)), atol=1e-2)      # test_grbcm.py:36 (its data has no noise)
+
+
+@pytest.mark.gpu
+def test_batched_diag_prediction_matches_the_per_expert_loop(golden, monkeypatch):
+    """Exact_GP.predict / GRBCM.predict(var="diag") of a batched model (round 5): every expert's K* in one launch, means and variances in
+    three, the committee's terms in one -- against the per-expert loop of rounds 1-4 (PG_PREDICT_SERIAL=1), BIT FOR BIT, and against the
+    oracle.  Cases: the reference's own test size (ten experts of 100 points, tests/test_gpr.py:59-100), ragged sizes with shared and
+    per-expert test points, shared training points under batched params, more test points than one chunk, a lazily inverted model."""
+    from pygpr_amd import gpr as _gpr
+
+    rng = np.random.default_rng(77)
+
+    def both(fn):
+        out_b = fn()
+        monkeypatch.setenv("PG_PREDICT_SERIAL", "1")
+        try:
+            out_s = fn()
+        finally:
+            monkeypatch.delenv("PG_PREDICT_SERIAL")
+        return out_b, out_s
+
+    for nc, n, d, m, per_expert_xp in ((10, 100, 3, 100, False), (3, 300, 5, 77, True), (4, 700, 16, 300, False)):
+        x = rng.random((nc, n, d))
+        y = np.sin(-x.sum(-1)) + 0.1 * rng.standard_normal((nc, n))
+        hp = np.stack([np.concatenate([[1.0 + 0.05 * c], 0.6 + 0.3 * rng.random(d), [0.1]]) for c in range(nc)])
+        xp = rng.random((nc, m, d)) if per_expert_xp else rng.random((m, d))
+        gp = pg.Exact_GP(T(x), T(y), se_wn(), eager_inverse=(nc != 3))
+        gp.set_params(T(hp))
+        for var in ("diag", "none"):
+            (mu_b, v_b), (mu_s, v_s) = both(lambda: gp.predict(T(xp), var=var))
+            assert gp._bat is not None
+            assert torch.equal(mu_b, mu_s)
+            if var == "diag":
+                assert torch.equal(v_b, v_s)
+        gp.predict(T(xp), var="diag")
+        assert gp.last_predict_batched
+        for c in range(nc):
+            mu_o, var_o = orc.gp_predict([orc.SE, orc.WN], hp[c], x[c], y[c], xp[c] if per_expert_xp else xp, "diag", form="direct")
+            np.testing.assert_allclose(N(mu_b[c]), mu_o, atol=1e-9)
+            np.testing.assert_allclose(N(v_b[c]), var_o, atol=1e-10)
+    # batched params on shared training points (x [n, d], params [nc, nhp]) and more test points than one chunk
+    monkeypatch.setattr(_gpr, "_CHUNK", 256)
+    n, d, m, nc = 200, 4, 700, 3
+    x = rng.random((n, d)); y = np.sin(-x.sum(-1)) + 0.1 * rng.standard_normal(n)
+    hp = np.stack([np.concatenate([[1.0], 0.5 + 0.2 * c + rng.random(d), [0.1]]) for c in range(nc)])
+    gp = pg.Exact_GP(T(x), T(y), se_wn())
+    gp.set_params(T(hp))
+    xp = rng.random((m, d))
+    (mu_b, v_b), (mu_s, v_s) = both(lambda: gp.predict(T(xp), var="diag"))
+    assert gp.last_predict_batched is False and mu_b.shape == (nc, m)      # (the serial run came last)
+    assert torch.equal(mu_b, mu_s) and torch.equal(v_b, v_s)
+    for c in range(nc):
+        mu_o, var_o = orc.gp_predict([orc.SE, orc.WN], hp[c], x, y, xp, "diag", form="direct")
+        np.testing.assert_allclose(N(mu_b[c]), mu_o, atol=1e-9)
+        np.testing.assert_allclose(N(v_b[c]), var_o, atol=1e-10)
+    # the committee: batched experts + one launch for all local terms, against the loop and the golden committee
+    g = golden("grbcm")
+    p = "g1_"
+    com = pg.GRBCM(T(g[p + "xl"]), T(g[p + "yl"]), T(g[p + "xg"]), T(g[p + "yg"]), se_wn())
+    com.gpg.set_params(T(g[p + "hpg"]))
+    com.gpl.set_params(T(g[p + "hpl"]))
+
+    def committee():
+        mu, var = com.predict(T(g[p + "xs"]), var="diag")
+        return mu, var, com.beta.clone(), com.prec.clone()
+
+    (mu_b, v_b, be_b, pr_b), (mu_s, v_s, be_s, pr_s) = both(committee)
+    assert torch.equal(mu_b, mu_s) and torch.equal(v_b, v_s) and torch.equal(be_b, be_s) and torch.equal(pr_b, pr_s)
+    np.testing.assert_allclose(N(mu_b), g[p + "mu"], atol=1e-10)
+    np.testing.assert_allclose(N(v_b), g[p + "var"], atol=1e-11)
+    np.testing.assert_allclose(N(be_b), g[p + "beta"], atol=1e-9)
