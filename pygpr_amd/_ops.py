@@ -330,9 +330,11 @@ class HipOps:
         hp_all [nexp | 1, nhp], work_all [nexp, (n_pad/64) m_pad].  kss is formed on the device from hp_all."""
         passes = _passes(spec)
         assert len(passes) == 1
-        self._chk(kt_all, alpha_all, mean_all, var_all, hp_all, work_all)
+        self._chk(kt_all, alpha_all, hp_all, work_all)
         nexp, m_pad, n_pad = kt_all.shape
         want_var = var_all is not None
+        for t in (mean_all, var_all):          # rows may be slices of longer rows (chunks of test points): unit stride inside a row
+            assert t is None or (t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] >= m_pad and (nexp == 1 or t.stride(0) >= m_pad))
         if want_var:
             assert minv_all.is_cuda and minv_all.stride(-1) == 1 and hp_all.dtype == torch.float64
         _lib.check(self.lib.pg_predict_mean_q_kt_batched(

@@ -2,6 +2,9 @@
 #include "common.h"
 #include "pygpr_hip.h"
 
+struct GradBatch {          // strides between batched experts of the gradient contraction (elements); all zero for one expert
+    long eX, ehp, eK, ea, epart, egrad;
+};
 template <typename T>
 int pg_kbuild(hipStream_t st, const pg_covspec& spec, const double* hp, const T* Xr, long ldr, int nr,
               const T* Xc, long ldc, int nc, int d, int symmetric, int lower_only, int accumulate, double jitter, T* K,

@@ -443,8 +443,11 @@ class Exact_GP(GPR):
         if diag:
             for e in experts:
                 self._minv(e)
-        mean_all = ops.empty(nb, m, dtype=self.dtype)
-        var_all = ops.empty(nb, m, dtype=self.dtype) if diag else None
+        # outputs: one fresh buffer per call, rows long enough for the padded last chunk -- the kernels write every chunk's means and
+        # variances straight into their place (no staging copies: at the reference's test sizes those were half the call)
+        mtot = ((m // _CHUNK) * _CHUNK + pad_to(m % _CHUNK)) if m % _CHUNK else m
+        mean_all = ops.empty(nb, mtot, dtype=self.dtype)
+        var_all = ops.empty(nb, mtot, dtype=self.dtype) if diag else None
         item = torch.empty(0, dtype=self.dtype).element_size()
         x_all = self._x_all
         for s in range(0, m, _CHUNK):
@@ -458,20 +461,17 @@ class Exact_GP(GPR):
             key = ("bat", grp, m_pad, n_pad, diag)
             if self._pbuf is None or self._pbuf[0] != key:
                 self._pbuf = None
-                self._pbuf = (key, ops.empty(grp, m_pad, n_pad, dtype=self.dtype), ops.empty(grp, (n_pad // 64) * m_pad, dtype=self.dtype),
-                              ops.empty(grp, m_pad, dtype=self.dtype), ops.empty(grp, m_pad, dtype=self.dtype) if diag else None)
-            _, kt, work, mu, vq = self._pbuf
+                self._pbuf = (key, ops.empty(grp, m_pad, n_pad, dtype=self.dtype), ops.empty(grp, (n_pad // 64) * m_pad, dtype=self.dtype))
+            _, kt, work = self._pbuf
             for b0 in range(0, nb, grp):
                 cnt = min(grp, nb - b0)
                 xr = xq if xq.dim() == 2 else (xq[b0: b0 + cnt] if xq.shape[0] > 1 else xq[0])
                 xc = x_all[b0: b0 + cnt] if x_all.shape[0] > 1 else x_all
                 ops.kernel_build_batched(spec, bat["hp"][b0: b0 + cnt], xr, xc, kt[:cnt])
-                ops.predict_mean_q_kt_batched(kt[:cnt], bat["minv"][b0: b0 + cnt] if diag else None, bat["alpha"][b0: b0 + cnt], mu[:cnt],
-                                              vq[:cnt] if diag else None, spec, bat["hp"][b0: b0 + cnt], work[:cnt])
-                mean_all[b0: b0 + cnt, s: s + mc] = mu[:cnt, :mc]
-                if diag:
-                    var_all[b0: b0 + cnt, s: s + mc] = vq[:cnt, :mc]
-        return [mean_all[b] for b in range(nb)], ([var_all[b] for b in range(nb)] if diag else [None] * nb)
+                ops.predict_mean_q_kt_batched(kt[:cnt], bat["minv"][b0: b0 + cnt] if diag else None, bat["alpha"][b0: b0 + cnt],
+                                              mean_all[b0: b0 + cnt, s: s + m_pad], var_all[b0: b0 + cnt, s: s + m_pad] if diag else None,
+                                              spec, bat["hp"][b0: b0 + cnt], work[:cnt])
+        return [mean_all[b, :m] for b in range(nb)], ([var_all[b, :m] for b in range(nb)] if diag else [None] * nb)
 
     def _predict_device(self, xpd, want):
         """Per-expert device tensors (mean[m], var[m] | cov[m,m] | None) for device-resident test points: xpd [m, d]
@@ -500,11 +500,14 @@ class Exact_GP(GPR):
         want = var if var in ("full", "diag") else "none"
         xpd = ops.to_device(xp if xp.dim() == 2 else xp.reshape(-1, xp.shape[-2], xp.shape[-1]), self.dtype)
         means, covs = self._predict_device(xpd, want)
-        ys = torch.stack(means).squeeze().to(xp.device)   # squeeze_(): drops every size-1 dim (gpr.py:87)
+        # (the batched prediction hands out rows of ONE fresh buffer: the stacked result is a view of it, no stacking kernel)
+        mstack = _stacked_rows(means) if len(means) > 1 else None
+        ys = (mstack if mstack is not None else torch.stack(means)).squeeze().to(xp.device)   # squeeze_(): drops every size-1 dim (gpr.py:87)
         if want == "none":
             covars = NotImplemented
         elif self.batched:
-            covars = torch.stack(covs).to(xp.device)
+            cstack = _stacked_rows(covs) if want == "diag" else None
+            covars = (cstack if cstack is not None else torch.stack(covs)).to(xp.device)
         else:
             covars = covs[0].contiguous().to(xp.device)
         return [ys, covars]

@@ -1424,3 +1424,130 @@ def test_batched_prediction_entry_points_match_the_one_expert_calls(ops):
             assert torch.equal(out_b, out_s) and torch.equal(beta_b, beta_s) and torch.equal(prec_b, prec_s)
             ref = sum(orc.grbcm_terms(host(mean_l[e, :m]), host(var_l[e, :m]), host(vg), e == first) for e in range(nexp))
             np.testing.assert_allclose(host(out_b), ref, rtol=1e-5 if dtype == torch.float32 else 1e-13)
+
+
+# --------------------------------------------------------------------------- matrix-pipe bodies (kmfma.hip)
+def _grad_inputs(ops, covs, hp, x, y, dtype):
+    """K^-1 (lower) and alpha of the model on the device, in `dtype`."""
+    from pygpr_amd._ops import pad_to
+
+    n, d = x.shape
+    npad = pad_to(n)
+    spec = _spec(covs, d)
+    hpd, xd = dev(hp), dev(x, dtype)
+    k = ops.empty(npad, npad, dtype=dtype)
+    invd = ops.potrf_workspace(npad, dtype)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    minv = ops.zeros(npad, npad, dtype=dtype)
+    ops.build_factor(spec, hpd, xd, k, invd, info, minv)
+    assert int(info.item()) == 0
+    ypad = ops.zeros(npad, dtype=dtype)
+    ypad[:n] = dev(y, dtype)
+    u, alpha = ops.empty(npad, dtype=dtype), ops.empty(npad, dtype=dtype)
+    ops.trmv(minv, ypad, u, 0)
+    ops.trmv(minv, u, alpha, 1, ops.empty((npad // 256 + 1) * npad, dtype=dtype))
+    kinv = ops.zeros(npad, npad, dtype=dtype)
+    ops.lauum(minv, kinv)
+    return spec, hpd, xd, kinv, alpha
+
+
+@pytest.mark.parametrize("kind", ["se", "m52"])
+@pytest.mark.parametrize("d", [2, 5, 8, 13, 16])
+def test_matrix_pipe_bodies_against_the_valu_bodies_and_the_oracle(ops, monkeypatch, kind, d):
+    """kmfma.hip (round 5): the covariance build and the gradient contraction with their pairwise products on the matrix pipe, against
+    (i) the VALU bodies of kbuild.hip on the same inputs (PG_KB_MFMA=0 / PG_GRAD_MFMA=0) and (ii) the direct-difference oracle -- fp64 at
+    the parity tolerances of the rest of the suite, fp32 at the 1e-3 class; mirrored, lower-only and cross builds of one configuration
+    agree bit for bit; the padding is the identity / zero."""
+    from pygpr_amd._ops import pad_to
+
+    rng = np.random.default_rng(100 * d + len(kind))
+    n, m = 333, 200
+    x, y = orc.synth(n, d, seed=d)
+    xp = rng.random((m, d))
+    covs = [orc.SE if kind == "se" else orc.M52, orc.WN]
+    hp = np.concatenate([[1.2], 0.4 + 0.8 * rng.random(d), [0.1]])
+    spec, npad, mpad = _spec(covs, d), pad_to(n), pad_to(m)
+    ref = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    ref_x = orc.kernel(covs, hp, x, xp, form="direct")            # [m, n]
+    for dtype, tol in ((torch.float64, 2e-14), (torch.float32, 4e-6)):
+        hpd, xd, xpd = dev(hp), dev(x, dtype), dev(xp, dtype)
+        out = {}
+        for mode in ("2", "0"):
+            monkeypatch.setenv("PG_KB_MFMA", mode)
+            full, low, cross = ops.empty(npad, npad, dtype=dtype), ops.zeros(npad, npad, dtype=dtype), ops.empty(mpad, npad, dtype=dtype)
+            ops.kernel_build(spec, hpd, xd, None, full, jitter=1e-7)
+            ops.kernel_build(spec, hpd, xd, None, low, lower_only=True, jitter=1e-7)
+            ops.kernel_build(spec, hpd, xpd, xd, cross)
+            out[mode] = (host(full), host(low), host(cross))
+        monkeypatch.delenv("PG_KB_MFMA")
+        full, low, cross = out["2"]
+        np.testing.assert_allclose(full[:n, :n], ref, atol=tol, rtol=tol)
+        np.testing.assert_allclose(cross[:m, :n], ref_x, atol=tol, rtol=tol)
+        np.testing.assert_allclose(full, out["0"][0], atol=tol, rtol=tol)
+        np.testing.assert_allclose(cross, out["0"][2], atol=tol, rtol=tol)
+        assert np.array_equal(full[:n, :n], full[:n, :n].T)                       # exactly symmetric
+        pad_ref = np.eye(npad); pad_ref[:n, :n] = full[:n, :n]
+        assert np.array_equal(full, pad_ref)                                      # identity padding
+        assert not cross[m:, :].any() and not cross[:, n:].any()                  # zero padding of a cross build
+        tl = np.tril_indices(npad)
+        assert np.array_equal(low[tl], full[tl])                                  # lower-only == mirrored on the lower triangle, bit for bit
+        assert not low[:64, 64:].any()                                            # tiles above the diagonal untouched
+        dgv = np.float64(np.float32(1.2 ** 2 + 0.1 ** 2 + 1e-7)) if dtype == torch.float32 else 1.2 ** 2 + 0.1 ** 2 + 1e-7
+        np.testing.assert_allclose(np.diag(full)[:n], dgv, rtol=2e-7 if dtype == torch.float32 else 1e-15)
+    # gradient contraction
+    loss_ref, grad_ref = orc.mle_loss_and_grad(covs, hp, x, y, "kinv", form="direct")
+    for dtype, rtol in ((torch.float64, 1e-9), (torch.float32, 3e-3)):
+        spec, hpd, xd, kinv, alpha = _grad_inputs(ops, covs, hp, x, y, dtype)
+        work = ops.empty(ops.nlml_grad_worksize(n, hp.size))
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PG_GRAD_MFMA", mode)
+            g = ops.zeros(hp.size)
+            ops.nlml_grad(spec, hpd, xd, n, kinv, alpha, g, work)
+            got[mode] = host(g)
+        monkeypatch.delenv("PG_GRAD_MFMA")
+        scale = np.abs(grad_ref).max()
+        np.testing.assert_allclose(got["1"], got["0"], rtol=rtol, atol=rtol * scale)
+        np.testing.assert_allclose(got["1"], grad_ref, rtol=10 * rtol if dtype == torch.float64 else rtol * 3, atol=(10 * rtol if dtype == torch.float64 else rtol * 3) * scale)
+
+
+def test_matrix_pipe_bodies_on_uncentred_and_batched_data(ops, monkeypatch):
+    """(i) Points shifted by 1e4: the matrix-pipe bodies work on coordinates relative to the first point, so build and gradient keep their
+    accuracy (the VALU fast body's expansion loses eps |x l|^2 there, the direct differences nothing); (ii) batched experts (blockIdx.z /
+    blockIdx.y = expert) give each expert the numbers of its one-expert call bit for bit."""
+    from pygpr_amd._ops import pad_to
+
+    rng = np.random.default_rng(5)
+    n, d = 300, 16
+    x, y = orc.synth(n, d, seed=3)
+    covs = [orc.SE, orc.WN]
+    hp = np.concatenate([[1.1], 0.4 + 0.3 * rng.random(d), [0.1]])
+    xs = x + 1.0e4
+    npad = pad_to(n)
+    k = ops.empty(npad, npad)
+    ops.kernel_build(_spec(covs, d), dev(hp), dev(xs), None, k, jitter=1e-7)
+    ref = orc.kernel(covs, hp, x, form="direct") + 1e-7 * np.eye(n)
+    np.testing.assert_allclose(host(k)[:n, :n], ref, atol=5e-11, rtol=0)          # the shift's own rounding (eps x 1e4 per coordinate), not eps x 1e8
+    _, grad_ref = orc.mle_loss_and_grad(covs, hp, x, y, "kinv", form="direct")
+    spec, hpd, xd, kinv, alpha = _grad_inputs(ops, covs, hp, x, y, torch.float64)
+    work = ops.empty(ops.nlml_grad_worksize(n, hp.size))
+    g = ops.zeros(hp.size)
+    ops.nlml_grad(spec, hpd, dev(xs), n, kinv, alpha, g, work)
+    np.testing.assert_allclose(host(g), grad_ref, rtol=1e-7, atol=1e-7 * np.abs(grad_ref).max())
+    # batched: three experts' gradients in one call against three calls
+    nexp = 3
+    hp_all = np.stack([hp * (1.0 + 0.05 * e) for e in range(nexp)])
+    x_all = np.stack([orc.synth(n, d, seed=10 + e)[0] for e in range(nexp)])
+    kinv_all, alpha_all = ops.zeros(nexp, npad, npad), ops.zeros(nexp, npad)
+    singles = []
+    for e in range(nexp):
+        ye = orc.synth(n, d, seed=10 + e)[1]
+        spec, hpd_e, xd_e, kinv_e, alpha_e = _grad_inputs(ops, covs, hp_all[e], x_all[e], ye, torch.float64)
+        kinv_all[e].copy_(kinv_e); alpha_all[e].copy_(alpha_e)
+        g = ops.zeros(hp.size)
+        ops.nlml_grad(spec, hpd_e, xd_e, n, kinv_e, alpha_e, g, work)
+        singles.append(host(g))
+    grad_all = ops.zeros(nexp, hp.size)
+    xd_all = dev(x_all)
+    ops.nlml_grad_batched(spec, dev(hp_all), xd_all, xd_all.stride(0), n, kinv_all, alpha_all, grad_all, ops.empty(nexp * ops.nlml_grad_worksize(n, hp.size)))
+    assert np.array_equal(host(grad_all), np.stack(singles))
