@@ -334,6 +334,12 @@ int pg_spin_probe(pg_handle h, int n, void* scratch, void* stream);
  * the coupled chain needs the look-ahead schedule, i.e. at least three outer panels; any caller stream works, the legacy
  * default stream included) -- tests / diagnostics */
 int pg_last_coupled_panels(pg_handle h);
+/* Experimental schedule of the coupled factorisation (part of tc.cholesky, gpr.py:69 / loss.py:97; OFF by default, PG_DEFER=1 in the
+ * environment switches it on for new handles): from n = 6144 the columns right of about n / 2 take the leading half's updates as deferred
+ * K = n/2-deep products beside the trailing half's chain instead of panel by panel.  Same factor to rounding; measured 3 % slower at
+ * n = 8192.  pg_last_deferred_panels: how many column panels of the handle's LAST factorisation were deferred. */
+int pg_set_deferred_block(pg_handle h, int on);
+int pg_last_deferred_panels(pg_handle h);
 
 /* one 128x128 Cholesky leaf (factor + inverse) on its own; ablate != 0 skips phases -- timing diagnostics only */
 int pg_leaf_raw(pg_handle h, int dtype, void* A, long lda, void* inv, long ldi, int* info, int ablate, void* stream);

@@ -93,6 +93,8 @@ _SIGS = {
     "pg_spin_probe": (_i, [_vp, _i, _vp, _vp]),
     "pg_chain_timeouts": (_i, [_vp]),
     "pg_last_coupled_panels": (_i, [_vp]),
+    "pg_last_deferred_panels": (_i, [_vp]),
+    "pg_set_deferred_block": (_i, [_vp, _i]),
     "pg_set_coupled_chain": (_i, [_vp, _i]),
     "pg_coupled_chain": (_i, [_vp]),
     "pg_leaf_raw": (_i, [_vp, _i, _vp, _l, _vp, _l, _vp, _i, _vp]),

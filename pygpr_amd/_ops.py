@@ -529,6 +529,12 @@ class HipOps:
     def last_coupled_panels(self):
         return int(self.lib.pg_last_coupled_panels(self.h))
 
+    def set_deferred_block(self, on):
+        _lib.check(self.lib.pg_set_deferred_block(self.h, int(on)), "pg_set_deferred_block")
+
+    def last_deferred_panels(self):
+        return int(self.lib.pg_last_deferred_panels(self.h))
+
     def leaf_raw(self, a, inv, info, ablate=0):
         self._chk(a, inv, info)
         _lib.check(self.lib.pg_leaf_raw(self.h, _code(a.dtype), _p(a), a.stride(0), _p(inv), inv.stride(0) if inv is not None else 0,

@@ -237,6 +237,7 @@ int pg_create(pg_handle* h) {
     PG_CHECK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
     c->rows = nullptr;
     c->last_coupled = 0;
+    c->defer = getenv("PG_DEFER") ? atoi(getenv("PG_DEFER")) : 0;
     c->lookahead = 1;
     {
         const char* e = getenv("PG_NBO");
@@ -862,6 +863,15 @@ int pg_coupled_chain(pg_handle h) { return h ? h->coupled : -1; }
 int pg_last_coupled_panels(pg_handle h) {
     if (!h) return -1;
     return h->last_coupled;
+}
+int pg_set_deferred_block(pg_handle h, int on) {
+    NEED(h, "null handle");
+    h->defer = on ? 1 : 0;
+    return 0;
+}
+int pg_last_deferred_panels(pg_handle h) {
+    if (!h) return -1;
+    return h->last_deferred;
 }
 int pg_profile_read(pg_handle h, double* flops, double* ms, long* launches) {
     NEED(h, "null handle");

@@ -29,6 +29,8 @@ struct pg_ctx {
     int coupled;              // the flag-coupled chain may be used (pg_set_coupled_chain; cleared by pg_create when kernels of the
                               // panel and rows streams do not run concurrently here, e.g. under a counter-collecting profiler)
     int last_coupled;         // panels the last factorisation ran on the flag-coupled chain (chainstep.hip); tests / diagnostics
+    int defer;                // deferred trailing block in the coupled factorisation (pg_set_deferred_block / PG_DEFER; default 0)
+    int last_deferred;        // column panels of the last factorisation whose updates by the first half came as deferred deep-K products (linalg.hip)
     int panel_mode;           // how the rows below an outer panel ride its 128-column steps (linalg.hip, PG_PANEL_MODE)
     int side_pending;         // side-stream work (pg_alpha_nlml_async) that the next reader of its outputs must wait for: ev[5]
     hipStream_t side_owner;   // the caller stream that work was forked from: only a join on THAT stream clears side_pending

@@ -14,7 +14,7 @@ template <typename T> struct GemmP {
     long lda, ldb, ldc;
     int M, N, K;      // multiples of the block tile / 16
     T alpha, beta;
-    int tri;          // 1: only tiles on or below the diagonal (BM == BN)
+    int tri;          // 1: only tiles on or below the diagonal (BM == BN; N < M: the leading N x N triangle + the full rows below it)
     int klo, khi;     // K-range from a triangular operand: 0 none, 1 follows the tile row, 2 the tile column
     int krev;         // klo launches: walk each tile's K range from its end downwards (all tiles start at the same k)
     long sA, sB, sC;  // batch strides (elements), grid.y = batch * nexp

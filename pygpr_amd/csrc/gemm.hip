@@ -92,6 +92,20 @@ __device__ __forceinline__ void gemm_decode(const GemmP<T>& p, int wg, int& ti, 
     // of different rows do not, and patches made of them fetched MORE (measured: lauum 59 -> 80 GB, 8 % slower).
     constexpr int GR = 8;
     const bool grouped = !(p.klo | p.khi | p.noxcd);
+    // tri with N < M: a trapezoid -- the lower triangle of the leading N x N block, then the full tile rows below it (the Cholesky's
+    // trailing update restricted to a column range, and the deferred block's column panels: linalg.hip)
+    int tmT = p.M / BM;                    // tile rows of the triangular part
+    if (p.tri && p.N / BN < tmT) {
+        const int tnA = p.N / BN, t0 = tnA * (tnA + 1) / 2;
+        if (wg >= t0) {                    // bands of GR full rows, column by column inside a band
+            const int w0 = wg - t0, band = w0 / (GR * tnA), r0 = band * GR;
+            const int rows = min(GR, tmT - tnA - r0), w = w0 - band * GR * tnA;
+            ti = tnA + r0 + w % rows;
+            tj = w / rows;
+            return;
+        }
+        tmT = tnA;
+    }
     if (p.tri && grouped) {
         // band g = tile rows [8g, 8g+8): 64 g + 36 tiles, the bands before it hold 32 g (g - 1) + 36 g
         int g = (int)((sqrtf(1024.0f + 128.0f * (float)wg) - 32.0f) / 64.0f);
@@ -99,7 +113,7 @@ __device__ __forceinline__ void gemm_decode(const GemmP<T>& p, int wg, int& ti, 
         while (32L * (g + 1) * g + 36L * (g + 1) <= wg) ++g;
         int w = wg - (int)(32L * g * (g - 1) + 36L * g);
         const int r0 = GR * g;
-        if (r0 + GR > p.M / BM) {          // ragged last band: row-major inside it
+        if (r0 + GR > tmT) {               // ragged last band: row-major inside it
             ti = r0;
             while (w >= ti + 1) { w -= ti + 1; ++ti; }
             tj = w;
@@ -363,7 +377,8 @@ static int launch(hipStream_t st, const GemmP<T>& p) {
         return -2;
     }
     const int tm = p.M / BM, tn = p.N / BN;
-    const long tiles = p.tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
+    if (p.tri && tn > tm) { pg_set_error("pg_gemm: tri with N = %d > M = %d", p.N, p.M); return -2; }
+    const long tiles = p.tri ? (long)tn * (tn + 1) / 2 + (long)(tm - tn) * tn : (long)tm * tn;   // (tn < tm: a trapezoid)
     if (tiles == 0 || p.batch == 0 || p.nexp == 0) return 0;
     if (p.batch > 65535) { pg_set_error("pg_gemm: batch=%d exceeds the grid's y limit", p.batch); return -2; }
     // grid.y = batch * nexp is limited to 65535: many small experts go in chunks of whole experts (each launch addresses its experts
@@ -410,7 +425,7 @@ double pg_gemm_flops(int variant, int M, int N, int K, int tri, int klo, int khi
     const int tm = M / BM, tn = N / BN;
     double f = 0;
     for (int ti = 0; ti < tm; ++ti)
-        for (int tj = 0; tj < (tri ? ti + 1 : tn); ++tj) {
+        for (int tj = 0; tj < (tri ? std::min(ti + 1, tn) : tn); ++tj) {
             int kb = 0, ke = K;
             if (klo == 1) kb = ti * BM;
             if (klo == 2) kb = tj * BN;

@@ -58,6 +58,20 @@ __device__ __forceinline__ double pg_exp_tab(double x, const double* tab) {
     return ldexp(p * tab[k & 31], k >> 5);
 }
 
+// sqrt(x) for x >= 0 in the Matern kernels' radial distance (a NaN stays a NaN): v_rsq_f64 refined by one Newton step on 1/sqrt and one on
+// the root itself (both quadratic: <= 1 ulp whatever the instruction's own precision) -- nine fp64 operations where the IEEE expansion
+// of sqrt() with its range scaling is about twenty.  Arguments below 1e-280 (a point against itself) return about 1e-140: every term
+// the kernels form from r then rounds exactly as with r = 0.
+__device__ __forceinline__ double pg_sqrt_pos(double x) {
+    x = (x < 1.0e-280) ? 1.0e-280 : x;
+    double y = __builtin_amdgcn_rsq(x);
+    const double t = __builtin_fma(-0.5 * x * y, y, 0.5);
+    y = __builtin_fma(y, t, y);
+    double r = x * y;
+    r = __builtin_fma(__builtin_fma(-r, r, x), 0.5 * y, r);
+    return r;
+}
+
 // Strip (tile row tr, first tile tcs, ntile tiles) of workgroup `b` of a 1-D grid: a workgroup walks up to S consecutive tiles of
 // one tile row.  Symmetric builds launch ONLY tiles on or below the diagonal (round 2 launched the full square and let the upper
 // half exit at once): column window [c0, c1) in tiles --

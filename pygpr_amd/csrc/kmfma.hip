@@ -21,6 +21,7 @@
 #include "kfun.h"
 #include "kmfma.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define KT 64
 
@@ -72,7 +73,7 @@ template <> struct KmVal<double, PG_KIND_MATERN52> {
     static __device__ __forceinline__ void run(double sq, double sig2, const double* tab, double& kv, double& base) {
         (void)sig2;
         const double s5 = 2.23606797749978969641;
-        const double r = sqrt(sq), e = pg_exp_tab(-s5 * r, tab);
+        const double r = pg_sqrt_pos(sq), e = pg_exp_tab(-s5 * r, tab);
         base = (1.0 + s5 * r) * e;
         kv = base + (5.0 / 3.0) * sq * e;
     }
@@ -230,7 +231,7 @@ template int pg_kbuild_mfma<float>(hipStream_t, const pg_covspec&, const double*
 // wave's columns j); they, the column sums of G and the sigma / noise sums are folded once per workgroup into part[blk][nhp]
 // (entries in the `presc` convention of pg_grad_reduce_kernel: sums of (l_k D_k)^2 terms).
 template <typename T, int DP, int KIND>
-__global__ __launch_bounds__(256) void pg_grad_mfma_kernel(pg_covspec spec, const double* __restrict__ hp, const T* __restrict__ X, long ldx, int n,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kernel(pg_covspec spec, const double* __restrict__ hp, const T* __restrict__ X, long ldx, int n,
                                                            int d, const T* __restrict__ Kinv, long ldk, const T* __restrict__ alpha,
                                                            double* __restrict__ part, int nhp, GradBatch gb, int gch) {
     typedef PtTile<T, DP> PT;
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(256) void pg_grad_mfma_kernel(pg_covspec spec, cons
     for (int idx = tid; idx < nhp; idx += 256) part[(long)blk * nhp + idx] = 0.0;
     if (r_begin >= tiles) return;
     __shared__ T xc[KT * LDP], ncs[KT], acs[KT], xr[2][KT * LDP], nrs[2][KT], ars[2][KT], cs[4][16];
-    __shared__ double tab[32], red[4][18];
+    __shared__ double tab[32], tab2[32], red[4][18];   // tab2 = 2 tab: the weight 2 of an interior tile rides in the covariance value
+    constexpr bool W2TAB = true;
+    const T sig2x2 = (T)(2.0 * hp[spec.off[0]] * hp[spec.off[0]]);
     const int o = spec.off[0];
     const int kk = tid % DP;
     const double sc = kk < d ? hp[o + 1 + kk] : 0.0;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void pg_grad_mfma_kernel(pg_covspec spec, cons
         acs[tid] = gc < n ? alpha[gc] : (T)0;
         apf = gr < n ? alpha[gr] : (T)0;
     }
-    if (sizeof(T) == 8 && tid < 32) tab[tid] = sg * sg * pg_exp2_32[tid];
+    if (sizeof(T) == 8 && tid < 32) { tab[tid] = sg * sg * pg_exp2_32[tid]; tab2[tid] = 2.0 * sg * sg * pg_exp2_32[tid]; }
     pcol.store(xc, sc, x0k, tid);
     prow.store(xr[0], sc, x0k, tid);
     if (tid < KT) ars[0][tid] = apf;
@@ -282,6 +285,33 @@ __global__ __launch_bounds__(256) void pg_grad_mfma_kernel(pg_covspec spec, cons
     T pgs = (T)0;                     // this lane's share of the column sums of G (column j0 + c16)
     double accs = 0.0, trw = 0.0;     // sum W K (the sigma entry), sum of the diagonal's W (the noise entries)
     const long jcol = min((long)gj, ldk - 1);
+    // K^-1 one block ahead of the arithmetic (a whole tile row ahead -- sixteen values per lane in flight -- was measured: no gain, the
+    // kernel is not bound by its loads: tools/probe_tile_bodies.py).  The blocks follow one another sixteen rows
+    // apart through the whole walk: one running pointer per accumulator register, advanced by 16 ldk per block (a 64-bit multiply per
+    // load before); only a block that reaches past the last real row takes the clamped form.
+    constexpr bool DEEP = false;
+    constexpr int NQ = DEEP ? 4 : 1;
+    const T* kp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kp[r] = Kinv + (long)(r_begin * KT + Mfma<T>::row(lane, r)) * ldk + jcol;
+    const long kstep = 16 * ldk;
+    int krow = r_begin * KT;          // first row of the block the pointers stand on
+    const int krow_end = r_end * KT;
+    T kq[NQ][4];                      // [block in flight][register]
+    auto kfetch = [&](T (&dst)[4]) {  // the block at krow -> dst, pointers on to the next one
+        if (krow + 16 <= n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = *kp[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = Kinv[(long)min(krow + Mfma<T>::row(lane, r), n - 1) * ldk + jcol];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kp[r] += kstep;
+        krow += 16;
+    };
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) kfetch(kq[q]);
     for (int tr = r_begin, it = 0; tr < r_end; ++tr, ++it) {
         const int cur = it & 1;
         const bool more = tr + 1 < r_end;
@@ -292,67 +322,71 @@ __global__ __launch_bounds__(256) void pg_grad_mfma_kernel(pg_covspec spec, cons
         const T* xb = xr[cur];
         const T* nb = nrs[cur];
         const T* ab = ars[cur];
-        const bool interior = tr > tc && (tr + 1) * KT <= n;       // strictly below the diagonal, inside the real points: weight 2 everywhere
-        // K^-1 of the first block; every block issues the next one's loads before its own arithmetic
-        T kin[4], kin_n[4];
+        T accs_t = (T)0;                                             // this tile row's share of sum W K
+        // one tile row = four 16 x 16 blocks.  INTERIOR (strictly below the diagonal, inside the real points: weight 2 everywhere) is
+        // a body without a single per-element test -- one basic block, so the four elements of a lane and the products of
+        // neighbouring blocks interleave; the diagonal tile and a ragged last tile take the general body.
+        auto tile_row = [&](auto interior_c) {
+            constexpr bool INTERIOR = decltype(interior_c)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kin[r] = Kinv[(long)min(tr * KT + Mfma<T>::row(lane, r), n - 1) * ldk + jcol];
+            for (int rb = 0; rb < 4; ++rb) {
+                const int i0 = 16 * rb;
+                T kin[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const int i0 = 16 * rb;
-            if (rb < 3) {
+                for (int r = 0; r < 4; ++r) kin[r] = kq[DEEP ? rb : 0][r];
+                if (krow < krow_end) kfetch(kq[DEEP ? rb : 0]);
+                T af[NS], nri[4], ai[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kin_n[r] = Kinv[(long)min(tr * KT + i0 + 16 + Mfma<T>::row(lane, r), n - 1) * ldk + jcol];
-            }
-            T af[NS], nri[4], ai[4];
+                for (int s = 0; s < NS; ++s) af[s] = xb[(i0 + c16) * LDP + 4 * s + g];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) af[s] = xb[(i0 + c16) * LDP + 4 * s + g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nri[r] = nb[i0 + Mfma<T>::row(lane, r)];
-                ai[r] = ab[i0 + Mfma<T>::row(lane, r)];
-            }
-            acc_t acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (T)-0.5 * (nri[r] + ncj);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc = Mfma<T>::run(af[s], bq[s], acc);
-            T gr_[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = tr * KT + i0 + Mfma<T>::row(lane, r);
-                T sq = (T)-2 * acc[r];
-                sq = sq < (T)0 ? (T)0 : sq;
-                T w = kin[r] - ai[r] * aj;
-                if (interior) w *= (T)2;
-                else {
-                    if (gi == gj && sq == sq) sq = (T)0;
-                    if (gi >= n || gj > gi) w = (T)0;
-                    else if (gj < gi) w *= (T)2;
-                    else trw += (double)w;
+                for (int r = 0; r < 4; ++r) {
+                    nri[r] = nb[i0 + Mfma<T>::row(lane, r)];
+                    ai[r] = ab[i0 + Mfma<T>::row(lane, r)];
                 }
-                T kv, base;
-                KmVal<T, KIND>::run(sq, sig2, tab, kv, base);
-                accs += (double)(w * kv);
-                gr_[r] = w * base;
-                pgs += gr_[r];
-            }
-            // G^T A and G^T A^2: register r of the block is the A operand of the k-step that covers its four rows
+                acc_t acc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int li = i0 + Mfma<T>::row(lane, r);
-                if (PACK) {
-                    const T xv = c16 < 2 * DP ? xb[li * LDP + (c16 < DP ? c16 : c16 - DP)] : (T)0;
-                    P = Mfma<T>::run(gr_[r], c16 < DP ? xv : xv * xv, P);
-                } else {
-                    const T xv = xb[li * LDP + c16];
-                    P = Mfma<T>::run(gr_[r], xv, P);
-                    P2 = Mfma<T>::run(gr_[r], xv * xv, P2);
+                for (int r = 0; r < 4; ++r) acc[r] = (T)-0.5 * (nri[r] + ncj);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc = Mfma<T>::run(af[s], bq[s], acc);
+                T gr_[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T sq = (T)-2 * acc[r];
+                    // (a squared exponential takes the expansion's rounding below zero as it is: exp(1e-16) = 1; a root does not)
+                    if (!INTERIOR || KIND != PG_KIND_RBF) sq = sq < (T)0 ? (T)0 : sq;
+                    T w = kin[r] - ai[r] * aj;
+                    if (INTERIOR) { if (!W2TAB) w *= (T)2; }
+                    else {
+                        const int gi = tr * KT + i0 + Mfma<T>::row(lane, r);
+                        if (gi == gj && sq == sq) sq = (T)0;
+                        if (gi >= n || gj > gi) w = (T)0;
+                        else if (gj < gi) w *= (T)2;
+                        else trw += (double)w;
+                    }
+                    T kv, base;
+                    KmVal<T, KIND>::run(sq, (INTERIOR && W2TAB) ? sig2x2 : sig2, (INTERIOR && W2TAB) ? tab2 : tab, kv, base);
+                    accs_t += w * kv;
+                    gr_[r] = w * base;
+                    pgs += gr_[r];
+                }
+                // G^T A and G^T A^2: register r of the block is the A operand of the k-step that covers its four rows
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int li = i0 + Mfma<T>::row(lane, r);
+                    if (PACK) {
+                        const T xv = c16 < 2 * DP ? xb[li * LDP + (c16 < DP ? c16 : c16 - DP)] : (T)0;
+                        P = Mfma<T>::run(gr_[r], c16 < DP ? xv : xv * xv, P);
+                    } else {
+                        const T xv = xb[li * LDP + c16];
+                        P = Mfma<T>::run(gr_[r], xv, P);
+                        P2 = Mfma<T>::run(gr_[r], xv * xv, P2);
+                    }
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) kin[r] = kin_n[r];
-        }
+        };
+        if (tr > tc && (tr + 1) * KT <= n) tile_row(std::true_type{});
+        else tile_row(std::false_type{});
+        accs += (double)accs_t;
         if (more) {
             prow.store(xr[cur ^ 1], sc, x0k, tid);
             if (tid < KT) ars[cur ^ 1][tid] = apf;
@@ -412,7 +446,7 @@ static int grad_mfma_launch(hipStream_t st, const pg_covspec& spec, const double
 template <typename T>
 int pg_grad_mfma(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, const T* Kinv, long ldk,
                  const T* alpha, double* part, int nhp, int tiles, const GradBatch& gb, int nexp, int* nblk) {
-    static const int gch_env = getenv("PG_GRAD_GCH") ? atoi(getenv("PG_GRAD_GCH")) : 8;
+    static const int gch_env = getenv("PG_GRAD_GCH") ? atoi(getenv("PG_GRAD_GCH")) : 16;   // 8 -> 16: 2-3 % (tools/probe_tile_bodies.py)
     const int gch = std::max(1, std::min(gch_env, 64));
     *nblk = tiles * ((tiles + gch - 1) / gch);
     const int kind = spec.kind[0];

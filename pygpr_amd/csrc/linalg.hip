@@ -704,6 +704,57 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
     static const int sa_rows = getenv("PG_CS_SA_ROWS") ? atoi(getenv("PG_CS_SA_ROWS")) : 0;   // measured: slower at every setting (n = 8192: off 4.77, 6144: 4.83, 4608: 4.90, 3072: 4.98, 2048: 5.06 ms): the panel period there is the trailing update's own time
     auto sa_after = [&](int o) { return sa_rows > 0 && o >= o_s && o + 1 < npan && (n - pb[o + 1]) > sa_rows; };
     std::vector<char> nf_split(npan + 1, 0);   // Sb(o) was launched as NEAR + FAR
+    // Deferred trailing block (round 5; pg_set_deferred_block / PG_DEFER=1, OFF by default: measured slower).
+    // A right-looking factorisation spends its throughput work first and ends in a chain-bound tail beside an idle chip (n = 8192: the
+    // last 19 of 64 steps).  With the switch on, the panels left of column cd = pb[od] (about n / 2) update only the columns left of
+    // cd2 = pb[oe]; the block right of cd2 receives everything those panels owe it LATER, panel by panel, as products K = cd deep
+    // ("BU(p)", one trapezoid launch per column panel p >= oe, its K range dealt to several workgroups per tile) on the update stream
+    // between the NEAR / FAR launches of the second half.  oe >= od + 1: the two-panel window of a rows kernel that works on a deferred
+    // panel then starts right of cd (nothing is applied twice).  Measured at n = 8192 (same box, potrf alone): 4.64 ms without, 4.78
+    // with -- the first half shrinks (3.3 -> 2.7 ms in the kernel trace), but a column panel of the deferred block is a few hundred
+    // tiles that run at 41-45 TFLOP/s beside the resident rows kernels (64 x 64 tiles; 128 x 128 with the K range dealt out: 5.36 ms),
+    // no better than the K = 384 updates they replace, and the second half waits for them (2.6 ms against 1.7).
+    static const int defer_min = getenv("PG_DEFER_MIN") ? atoi(getenv("PG_DEFER_MIN")) : 6144;
+    static const double defer_frac = getenv("PG_DEFER_FRAC") ? atof(getenv("PG_DEFER_FRAC")) : 0.5;
+    static const int defer_gap = getenv("PG_DEFER_GAP") ? std::max(1, atoi(getenv("PG_DEFER_GAP"))) : 1;
+    static const int defer_lead = getenv("PG_DEFER_LEAD") ? std::max(1, atoi(getenv("PG_DEFER_LEAD"))) : 3;
+    static const int nf_env0 = getenv("PG_CS_NEARFAR") ? atoi(getenv("PG_CS_NEARFAR")) : 1;
+    int od = -1, oe = -1, next_bu = 0;
+    if (ctx->defer && coupled && o_s == 0 && nexp == 1 && n >= defer_min && nf_env0 && sa_rows == 0) {
+        int o = 0;
+        while (o < npan && pb[o] < (int)(defer_frac * n)) ++o;
+        if (o >= 3 && o + defer_gap + 2 < npan) { od = o; oe = o + defer_gap; next_bu = oe; }
+    }
+    const bool defer = od > 0;
+    const int cd = defer ? pb[od] : 0, cd2 = defer ? pb[oe] : 0;
+    ctx->last_deferred = defer ? npan - oe : 0;
+    auto launch_bu = [&](int p) -> int {   // A[pb[p]:, panel p] -= L[pb[p]:, 0:cd] L[panel p, 0:cd]^T, lower tiles
+        GemmP<T> q = gp0<T>(); q.info = info;
+        q.M = n - pb[p]; q.N = pb[p + 1] - pb[p]; q.K = cd;
+        q.A = A + (long)pb[p] * lda; q.lda = lda; q.B = q.A; q.ldb = lda; q.C = A + (long)pb[p] * lda + pb[p]; q.ldc = lda;
+        q.alpha = (T)-1; q.beta = (T)1; q.tri = 1;
+        static const long bu_thresh = getenv("PG_BU_TILE_THRESH") ? atol(getenv("PG_BU_TILE_THRESH")) : 1024;
+        static const long bu_ksplit = getenv("PG_BU_KSPLIT") ? atol(getenv("PG_BU_KSPLIT")) : 1200;   // workgroups a launch should have
+        const long tiles = (long)(q.M / 128) * (q.N / 128);
+        const int variant = tiles < bu_thresh ? GEMM_NT_64 : GEMM_NT_128;
+        // A panel of the deferred block is a few hundred tiles, each K = cd deep: one workgroup per tile walks 4224 columns in 210 us
+        // whatever the launch's size.  The K range is dealt to `ks` workgroups per tile (the launch's batch dimension, all adding into
+        // the same C through the no-return fp64 atomics of the beta = 1 epilogue).
+        int ks = 1;
+        if (sizeof(T) == 8 && bu_ksplit > 0 && !ctx->no_atomic_c) {
+            const long bt = variant == GEMM_NT_64 ? 64 : 128, tn_ = q.N / bt, tm_ = q.M / bt;
+            const long wgs = tn_ * (tn_ + 1) / 2 + (tm_ - tn_) * tn_;
+            for (int k = 2; k <= 8; ++k)
+                if (cd % (k * 32) == 0 && wgs * (k - 1) < bu_ksplit) ks = k;
+        }
+        if (ks > 1) { q.K = cd / ks; q.batch = ks; q.sA = q.sB = cd / ks; q.sC = 0; }
+        int r = pg_gemm<T>(ctx, us, variant, q);
+        if (r) return r;
+        hipEvent_t e;
+        if ((r = pool_event(ctx, 10 + 4 * npan + p, &e))) return r;   // ev_bu[p]
+        PG_CHECK(hipEventRecord(e, us));
+        return 0;
+    };
     for (int o = 0; o < npan; ++o) {
         const int o0 = pb[o], oend = pb[o + 1];
         const bool cp = o >= o_s;
@@ -733,6 +784,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
                     // (its NEAR launch when that panel was a coupled one: nf_split[oc - 2])
                     if ((rc = pool_event(ctx, nf_split[oc - 2] ? 9 + 3 * npan + (oc - 2) : 2 + 2 * (oc - 2) + 1, &ev))) return rc;
                     PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+                    if (defer && oc >= oe) {                 // a deferred panel: what the first half owes it arrives as BU(oc)
+                        if ((rc = pool_event(ctx, 10 + 4 * npan + oc, &ev))) return rc;
+                        PG_CHECK(hipStreamWaitEvent(rs, ev, 0));
+                    }
                 }
                 if (c == oend && oc == 1 && build_split && !last_sa) {   // first touch of a column the folded build wrote on the update stream
                     if ((rc = pool_event(ctx, 7 + 2 * npan, &ev))) return rc;
@@ -857,25 +912,30 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
         const int o3 = (o + 3 <= npan) ? pb[o + 3] : n;
         const bool near_far = cp && nf_env && la && m2 > 0 && o3 < n;
         if (near_far) {
-            nf_split[o] = 1;
+            const bool dfr = defer && o < od;              // a panel of the first half: nothing right of cd2
             GemmP<T> p = gp0<T>(); p.info = info;
-            p.M = n - o2; p.N = o3 - o2; p.K = oend - o0;
-            p.A = A + (long)o2 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o2 * lda + o2; p.ldc = lda;
-            p.alpha = (T)-1; p.beta = (T)1;
-            batched(p, eA, eA, eA);
-            const long tiles = (long)(p.M / 128) * (p.N / 128) * nexp;
-            if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
-            if ((rc = pool_event(ctx, 9 + 3 * npan + o, &ev))) return rc;   // ev_near[o]
-            PG_CHECK(hipEventRecord(ev, us));
+            if (!(dfr && o + 2 >= oe)) {
+                nf_split[o] = 1;
+                p.M = n - o2; p.N = o3 - o2; p.K = oend - o0;
+                p.A = A + (long)o2 * lda + o0; p.lda = lda; p.B = p.A; p.ldb = lda; p.C = A + (long)o2 * lda + o2; p.ldc = lda;
+                p.alpha = (T)-1; p.beta = (T)1;
+                batched(p, eA, eA, eA);
+                const long tiles = (long)(p.M / 128) * (p.N / 128) * nexp;
+                if ((rc = pg_gemm<T>(ctx, us, tiles < 1024 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+                if ((rc = pool_event(ctx, 9 + 3 * npan + o, &ev))) return rc;   // ev_near[o]
+                PG_CHECK(hipEventRecord(ev, us));
+            }
             T* P = A + (long)o3 * lda + o0;
             p = gp0<T>(); p.info = info;
             p.M = p.N = n - o3; p.K = oend - o0; p.A = P; p.lda = lda; p.B = P; p.ldb = lda;
             p.C = A + (long)o3 * lda + o3; p.ldc = lda;
             p.alpha = (T)-1; p.beta = (T)1; p.tri = 1;
+            if (dfr) p.N = std::max(0, cd2 - o3);          // the trapezoid left of cd2 (all rows)
             batched(p, eA, eA, eA);
-            const long ftiles = (long)(p.M / 128) * (p.M / 128 + 1) / 2 * nexp;
+            const long tn_ = p.N / 128, tm_ = p.M / 128;
+            const long ftiles = (tn_ * (tn_ + 1) / 2 + (tm_ - tn_) * tn_) * nexp;
             static const long sb_thresh2 = getenv("PG_SB_TILE_THRESH") ? atol(getenv("PG_SB_TILE_THRESH")) : 2048;
-            if ((rc = pg_gemm<T>(ctx, us, ftiles < sb_thresh2 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
+            if (p.N > 0 && (rc = pg_gemm<T>(ctx, us, ftiles < sb_thresh2 ? GEMM_NT_64 : GEMM_NT_128, p))) return rc;
         } else if (m2 > 0) {  // Sb(o)
             T* P = A + (long)o2 * lda + o0;
             GemmP<T> p = gp0<T>(); p.info = info;
@@ -892,6 +952,10 @@ int pg_potrf_t(pg_ctx* ctx, hipStream_t st, int n, T* A, long lda, T* invD, int*
         if (la) {
             if ((rc = pool_event(ctx, 2 + 2 * o + 1, &ev))) return rc;   // ev_sb[o]
             PG_CHECK(hipEventRecord(ev, us));
+        }
+        if (defer && o >= od - 1) {   // the first half is final (ev_chain[od - 1], waited for above): the deferred block's column panels
+            for (int i = 0; i < (o == od - 1 ? defer_lead : 1) && next_bu < npan; ++i)
+                if ((rc = launch_bu(next_bu++))) return rc;
         }
     }
     if (la) {   // join both streams back onto the caller's stream

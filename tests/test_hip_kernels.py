@@ -1,5 +1,6 @@
 """GPU parity tests of the individual C-ABI entry points (through ctypes) against NumPy / the CPU oracle.
 fp64 tolerances are stated per test; fp32 runs are compared with the fp64 answer at 1e-3 class."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1551,3 +1552,66 @@ def test_matrix_pipe_bodies_on_uncentred_and_batched_data(ops, monkeypatch):
     xd_all = dev(x_all)
     ops.nlml_grad_batched(spec, dev(hp_all), xd_all, xd_all.stride(0), n, kinv_all, alpha_all, grad_all, ops.empty(nexp * ops.nlml_grad_worksize(n, hp.size)))
     assert np.array_equal(host(grad_all), np.stack(singles))
+
+
+@pytest.mark.parametrize("variant_name", ["GEMM_NT", "GEMM_NT_64"])
+@pytest.mark.parametrize("tm,tn", [(5, 3), (20, 3), (23, 9), (9, 8)])
+def test_gemm_trapezoid_tiles(ops, variant_name, tm, tn):
+    """Round 5: tri = 1 with N < M is a trapezoid -- the lower triangle of the leading N x N block and the full tile rows below it (the
+    restricted trailing update and the deferred block's column panels of the factorisation).  Against NumPy on the tiles it covers,
+    bit for bit against the same product as a square triangle + a rectangle, and nothing above the diagonal tiles is touched."""
+    from pygpr_amd import _lib
+
+    variant = getattr(_lib, variant_name)
+    g = torch.Generator(device="cuda").manual_seed(100 * tm + tn)
+    m, n, k = 128 * tm, 128 * tn, 256
+    a = torch.randn(m, k, device="cuda", dtype=torch.float64, generator=g)
+    c0 = torch.randn(m, n, device="cuda", dtype=torch.float64, generator=g)
+    c1, c2 = c0.clone(), c0.clone()
+    ops.gemm_raw(variant, m, n, k, -1.0, a, a[:n], 1.0, c1, tri=1)
+    ops.gemm_raw(variant, n, n, k, -1.0, a[:n], a[:n], 1.0, c2[:n], tri=1)
+    ops.gemm_raw(variant, m - n, n, k, -1.0, a[n:], a[:n], 1.0, c2[n:])
+    bs = 128 if variant_name == "GEMM_NT" else 64
+    mask = torch.ones(m, n, dtype=torch.bool, device="cuda")
+    for i in range(0, n, bs):
+        mask[i:i + bs, i + bs:] = False                       # tiles strictly above the diagonal
+    assert torch.equal(c1[mask], c2[mask])
+    assert torch.equal(c1[~mask], c0[~mask])
+    ref = host(c0) - host(a) @ host(a[:n]).T
+    low = np.tril(np.ones((m, n), dtype=bool))
+    np.testing.assert_allclose(host(c1)[low], ref[low], atol=1e-11)
+
+
+@pytest.mark.parametrize("n", [6144, 8192])
+def test_potrf_deferred_trailing_block(ops, n):
+    """Round 5, experimental schedule (pg_set_deferred_block; off by default -- measured slower): the coupled chain's first half (columns
+    left of about n / 2) updates only the columns up to one panel past the split; the block right of it takes those updates later as
+    K = n/2-deep products beside the second half's chain (pg_last_deferred_panels > 0).  The factor agrees with LAPACK's and with the
+    default schedule's to rounding; the fused inverse is the factor's inverse."""
+    rng = np.random.default_rng(n)
+    a = spd(n, rng)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    invd = ops.potrf_workspace(n, torch.float64)
+    ad0 = dev(a)
+    ops.potrf(ad0, invd, info)
+    assert ops.last_deferred_panels() == 0
+    ref = np.linalg.cholesky(a)
+    scale = np.abs(ref).max()
+    ops.set_deferred_block(1)
+    try:
+        ad = dev(a)
+        ops.potrf(ad, invd, info)
+        assert int(info.item()) == 0
+        if ops.coupled_chain():
+            assert ops.last_deferred_panels() > 0
+        L = np.tril(host(ad))
+        np.testing.assert_allclose(L, ref, rtol=0, atol=1e-11 * scale)
+        np.testing.assert_allclose(L, np.tril(host(ad0)), rtol=0, atol=1e-11 * scale)
+        ad3, minv = dev(a), ops.empty(n, n)
+        ops.potrf_trtri(ad3, invd, info, minv)
+        assert int(info.item()) == 0
+        mi = np.tril(host(minv))
+        r = mi[-512:] @ ref - np.eye(n)[-512:]
+        assert np.abs(r).max() < 1e-9
+    finally:
+        ops.set_deferred_block(0)
