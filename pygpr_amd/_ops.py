@@ -164,7 +164,8 @@ class HipOps:
     def build_factor_batched(self, spec, hp_all, x_all, x_stride, a_all, invd_all, info_all, minv_all=None, jitter=JITTER):
         """The same for nexp experts of one size in ONE call (pg_build_potrf_trtri_batched): hp_all [nexp, nhp], x_all [nexp | 1, n, d]
         (x_stride = 0 shares the points), a_all [nexp, n_pad, n_pad], invd_all [nexp, pg_potrf_worksize], info_all [nexp] int32,
-        minv_all [nexp, n_pad, n_pad] or None.  Every launch covers all experts; classic chain."""
+        minv_all [nexp, n_pad, n_pad] or None.  Every launch covers all experts; the flag-coupled chain where the batch is still
+        latency-bound (experts of at least 2048 points, at most 24576 rows in all), the classic chain otherwise."""
         passes = _passes(spec)
         assert len(passes) == 1
         self._chk(hp_all, x_all, a_all, invd_all, info_all, minv_all)

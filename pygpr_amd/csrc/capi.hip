@@ -31,6 +31,7 @@ static void release_ctx(pg_ctx* h) {
     for (int i = 0; i < h->npool; ++i) (void)hipEventDestroy(h->pool[i]);
     free(h->pool);
     if (h->tmo_host) (void)hipHostFree(h->tmo_host);
+    if (h->probe_words) (void)hipHostFree(h->probe_words);
     delete h;
 }
 
@@ -165,11 +166,14 @@ __global__ void pg_probe_wait_kernel(int* flag, int* seen) {
 __global__ void pg_probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 static int probe_concurrent_queues(pg_ctx* c) {
-    int* words = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&words), 64, hipHostMallocMapped) != hipSuccess) {
+    // (the words live as long as the handle: a re-arm inside an enqueueing entry point then costs the probe's two stream
+    //  synchronisations, not a pinned allocation and its device-wide release as well)
+    if (!c->probe_words && hipHostMalloc(reinterpret_cast<void**>(&c->probe_words), 64, hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
+        c->probe_words = nullptr;
         return 0;
     }
+    int* words = c->probe_words;
     words[0] = 0;
     words[1] = 0;
     int* dwords = nullptr;
@@ -180,7 +184,6 @@ static int probe_concurrent_queues(pg_ctx* c) {
         if (hipStreamSynchronize(c->aux) == hipSuccess && hipStreamSynchronize(c->rows) == hipSuccess) ok = words[1] == 1;
     }
     (void)hipGetLastError();
-    (void)hipHostFree(words);
     return ok;
 }
 
@@ -188,6 +191,10 @@ static int probe_concurrent_queues(pg_ctx* c) {
 // again (2 ms at most, once) and takes the coupled chain back: the cause on record (profiles/r03_bench_n2_gloo_rehearsal.json: another
 // process's resident kernels on the same GPU) is transient, the downgrade should be too.
 static void maybe_rearm(pg_ctx* h) {
+    if (h && h->coupled && h->rearms > 0 && h->rearm_cur > h->rearm_after && ++h->calls_since_rearm > h->rearm_cur) {
+        h->rearm_cur = h->rearm_after;      // the re-armed chain ran cleanly for a whole back-off distance: forget the back-off
+        h->calls_since_rearm = 0;
+    }
     if (!h || !h->tmo_off || h->coupled || h->rearm_after <= 0) return;
     if (h->rearm_cur < h->rearm_after) h->rearm_cur = h->rearm_after;
     if (++h->calls_since_tmo <= h->rearm_cur) return;
@@ -196,6 +203,7 @@ static void maybe_rearm(pg_ctx* h) {
         h->coupled = 1;
         h->tmo_off = 0;
         h->rearms += 1;
+        h->calls_since_rearm = 0;
     }
 }
 
@@ -428,6 +436,7 @@ int pg_build_potrf_trtri_batched(pg_handle h, int dtype, const pg_covspec* spec,
     NEED(inv_stride >= pg_potrf_worksize_impl(n_pad) || nexp == 1, "experts' workspaces overlap (stride < pg_potrf_worksize)");
     NEED(!Minv || (ldm >= n_pad && (m_stride >= (long)n_pad * ldm || nexp == 1)), "experts' inverses overlap");
     NEED(lda % (dtype == PG_F64 ? 2 : 4) == 0, "lda must keep rows 16-byte aligned");
+    maybe_rearm(h);      // a batched-only workload counts towards the re-arm like the single-matrix calls (one per call)
     AtomicGuard ag(h, A);
     DISPATCH(dtype,
              potrf_batched_t<double>(h, ST(stream), spec, hp, hp_stride, X, ldx, x_stride, n, d, jitter, A, lda, a_stride, n_pad, inv_diag,
@@ -838,6 +847,8 @@ int pg_set_coupled_chain(pg_handle h, int on) {
     }
     h->tmo_off = 0;
     h->rearm_cur = h->rearm_after;
+    h->rearms_seen = h->rearms;      // an explicit switch forgets the back-off's history: the next time-out starts from rearm_after again
+    h->calls_since_rearm = 0;
     if (!on) {
         // off also RELEASES the rows stream (the handle then owns two streams)
         if (h->rows) {
@@ -891,6 +902,8 @@ int pg_set_rearm_after(pg_handle h, int calls) {
     NEED(calls >= 0, "calls must be >= 0 (0: never re-arm automatically)");
     h->rearm_after = calls;
     h->rearm_cur = calls;
+    h->rearms_seen = h->rearms;
+    h->calls_since_rearm = 0;
     return 0;
 }
 int pg_chain_rearms(pg_handle h) { return h ? h->rearms : -1; }

@@ -45,6 +45,9 @@ struct pg_ctx {
     int rearms_seen;          // re-arms already answered by a back-off
     int rearm_cur;            // the current distance: doubled (up to 4096) by every time-out that follows a re-arm, so that a GPU shared for
                               // good with another process' resident kernels costs one wait budget ever more rarely, not every rearm_after calls
+    int calls_since_rearm;    // factorisations since the last automatic re-arm: a re-armed chain that survives rearm_cur of them has
+                              // earned the short distance back (the back-off decays)
+    int* probe_words;         // pinned words of the queue probe, allocated once per handle (pg_create's probe and every re-arm use them)
     int chain_epoch;          // counts the factorisations that took the coupled chain; an expiry reports its call's number
     int counted_epoch;        // the last epoch whose time-out was counted
     int no_atomic_c;          // set for the duration of an entry point whose C operand is not plain device memory

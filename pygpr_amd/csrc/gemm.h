@@ -14,7 +14,10 @@ template <typename T> struct GemmP {
     long lda, ldb, ldc;
     int M, N, K;      // multiples of the block tile / 16
     T alpha, beta;
-    int tri;          // 1: only tiles on or below the diagonal (BM == BN; N < M: the leading N x N triangle + the full rows below it)
+    int tri;          // 1: only tiles on or below the diagonal (BM == BN; N < M: the leading N x N triangle + the full rows below it).
+                      // What lies strictly ABOVE the diagonal inside the diagonal tiles is unspecified afterwards: whole 128 x 128 tiles
+                      // update it, 64 x 64 tiles and the quarter tiles of a mixed launch do not.  Consumers (the leaf, symmetrize, the
+                      // triangular products) read the lower triangle only: test_factor_ignores_the_upper_triangle.
     int klo, khi;     // K-range from a triangular operand: 0 none, 1 follows the tile row, 2 the tile column
     int krev;         // klo launches: walk each tile's K range from its end downwards (all tiles start at the same k)
     long sA, sB, sC;  // batch strides (elements), grid.y = batch * nexp

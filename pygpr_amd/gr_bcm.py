@@ -194,19 +194,24 @@ class GRBCM(GPR):
         mp = pad_to(m)
         # the owned experts' m x m inversions in ONE batched call per step (round 4: eight 2048 x 2048 inversions 9.8 -> about 3 ms)
         # while the matrices are small enough for the batched schedule to win (gpr.py's rule for batched fits)
-        # (the global expert's covariance rides along as the last matrix of the batch: it is needed after the all-reduce only, but it is
-        # known now, and one more matrix in the batch costs a fraction of an inversion of its own)
+        # (one process: the global expert's covariance rides along as the last matrix of the batch -- it is needed after the all-reduce
+        # only, but it is known now, and one more matrix in the batch costs a fraction of an inversion of its own.  Several ranks: the
+        # batch's schedule depends on how many experts a rank owns (tile variants, coupled or classic chain), so the replicated
+        # global expert is inverted by the SAME single-matrix call on every rank: with uneven ownership the aggregated covariance
+        # stays bit-identical across the replicas)
         together = 1 <= len(covs_l) and mp <= _AGG_BATCH_MAX
+        ride = together and not (self.distributed and self.world > 1)
 
         def enqueue():
             acc = None
             infos = []
             if together:
-                stack = ops.empty(len(covs_l) + 1, mp, mp, dtype=cov_g.dtype)
-                for c, cov_c in enumerate(list(covs_l) + [cov_g]):
+                stack = ops.empty(len(covs_l) + (1 if ride else 0), mp, mp, dtype=cov_g.dtype)
+                for c, cov_c in enumerate(list(covs_l) + ([cov_g] if ride else [])):
                     self._padded_spd(cov_c, out=stack[c])
                 _, info_all = ops.spd_inverse_lower_batched(stack)
-                state["p0"] = stack[len(covs_l)]
+                if ride:
+                    state["p0"] = stack[len(covs_l)]
                 acc = ops.empty(mp, mp, dtype=cov_g.dtype)
                 for c in range(len(covs_l)):
                     ops.grbcm_weighted_prec(stack[c], self.beta[c + 1].contiguous(), acc, m, c > 0)

@@ -1243,6 +1243,59 @@ def test_a_timeout_is_temporary_the_handle_rearms_itself(ops):
 
 
 @pytest.mark.gpu
+def test_rearm_counts_batched_calls_and_the_backoff_decays(ops):
+    """Round 5 (ADVICE): (i) pg_build_potrf_trtri_batched counts towards the automatic re-arm like the single-matrix calls -- a
+    batched-only workload (MLE on a batched model) gets the coupled chain back after K calls; (ii) the back-off does not ratchet: a
+    re-armed chain that ran cleanly for a whole back-off distance has the short distance again, so the NEXT time-out doubles K, not 2K."""
+    n, nexp = 2048, 2
+    rng = np.random.default_rng(31)
+    a = spd(n, rng)
+    chol = np.linalg.cholesky(a)
+    assert ops.coupled_chain() == 1
+    rearms = ops.chain_rearms()
+
+    def batched():
+        a_all = dev(np.stack([a, a]))
+        invd_all = ops.empty(nexp, ops.potrf_worksize(n, torch.float64))
+        info_all = torch.zeros(nexp, dtype=torch.int32, device="cuda")
+        ops.potrf_trtri_batched(a_all, invd_all, info_all, None)
+        coupled = ops.last_coupled_panels()
+        torch.cuda.synchronize()
+        assert not info_all.any().item()
+        np.testing.assert_allclose(np.tril(host(a_all[1])), chol, atol=1e-11)
+        return coupled
+
+    def time_out():
+        ops.set_spin_budget(-1)
+        _, _, info, _ = _potrf_on_compute_stream(ops, a)
+        ops.set_spin_budget(0)
+        before = ops.chain_timeouts()        # (an entry point that polls the pinned time-out word)
+        assert info == -1 and before >= 1 and ops.coupled_chain() == 0
+
+    ops.set_rearm_after(2)
+    try:
+        time_out()
+        for _ in range(2):
+            assert batched() == 0 and ops.chain_rearms() == rearms
+        assert batched() > 0 and ops.coupled_chain() == 1 and ops.chain_rearms() == rearms + 1     # the third batched call re-arms
+        time_out()                                   # follows a re-arm: distance 4
+        for _ in range(4):
+            assert _potrf_on_compute_stream(ops, a)[3] == 0
+        assert _potrf_on_compute_stream(ops, a)[3] > 0 and ops.chain_rearms() == rearms + 2
+        for _ in range(5):                           # more clean coupled calls than the back-off distance: it decays to 2
+            assert _potrf_on_compute_stream(ops, a)[3] > 0
+        time_out()                                   # doubles 2, not 4
+        for _ in range(4):
+            assert _potrf_on_compute_stream(ops, a)[3] == 0 and ops.chain_rearms() == rearms + 2
+        assert _potrf_on_compute_stream(ops, a)[3] > 0 and ops.chain_rearms() == rearms + 3
+    finally:
+        ops.set_rearm_after(8)
+        ops.set_spin_budget(0)
+        ops.set_coupled_chain(1)
+    assert ops.coupled_chain() == 1
+
+
+@pytest.mark.gpu
 def test_wait_budget_is_scaled_to_the_call(ops):
     """The default budget of one wait is 20x the call's classic-chain estimate, at least 50 ms -- not round 3's flat 2 s (70x a whole
     N = 16384 factorisation; in a lock-step all-reduce one rank's stall is every rank's).  The figures, and a REAL wait on a flag nobody
@@ -1615,3 +1668,28 @@ def test_potrf_deferred_trailing_block(ops, n):
         assert np.abs(r).max() < 1e-9
     finally:
         ops.set_deferred_block(0)
+
+
+@pytest.mark.parametrize("n", [512, 1536, 4096])
+def test_factor_ignores_the_upper_triangle(ops, n):
+    """ADVICE (round 4): with tri = 1 the updates leave what lies strictly above the diagonal unspecified (whole 128 x 128 diagonal tiles
+    update their upper quarter, 64 x 64 tiles and a mixed launch's quarter tiles do not).  No consumer may read it: a matrix whose strictly
+    upper triangle is POISONED (NaN) factorises to the same bits as the clean one -- the lower triangle of the factor, the diagonal
+    blocks' inverses, the fused triangular inverse and K^-1 = L^-T L^-1."""
+    rng = np.random.default_rng(7 + n)
+    a = spd(n, rng)
+    poisoned = a.copy()
+    poisoned[np.triu_indices(n, 1)] = np.nan
+    out = []
+    for m in (a, poisoned):
+        ad, minv, kinv = dev(m), ops.zeros(n, n), ops.zeros(n, n)
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        invd = ops.potrf_workspace(n, torch.float64)
+        ops.potrf_trtri(ad, invd, info, minv)
+        assert int(info.item()) == 0
+        ops.lauum(minv, kinv)
+        out.append((np.tril(host(ad)), host(invd[: n * 128]).copy(), np.tril(host(minv)), np.tril(host(kinv))))
+    for clean, dirty in zip(*out):
+        assert not np.isnan(dirty).any()
+        assert np.array_equal(clean, dirty)
+    np.testing.assert_allclose(out[1][0], np.linalg.cholesky(a), atol=1e-11)
