@@ -66,8 +66,13 @@ template <> struct KmVal<double, PG_KIND_RBF> {
         kv = base = pg_exp_tab(-sq, tab);           // sigma^2 folded into the table
     }
 };
+// fp32: the hardware's own exponential and root (v_exp_f32 on x log2 e, v_sqrt_f32: about 1 ulp each, the argument's rounding adds
+// |x| 2^-24 relative) -- the library forms cost some fifteen and eight instructions per element, which is what bound the fp32 bodies
+// (VALU issue: the fp32 matrix pipe runs beside it).  2-3 ulp in all, inside the fp32 tolerances of the suite (4e-6 on K).
+__device__ __forceinline__ float km_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float km_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <> struct KmVal<float, PG_KIND_RBF> {
-    static __device__ __forceinline__ void run(float sq, float sig2, const double*, float& kv, float& base) { kv = base = sig2 * expf(-sq); }
+    static __device__ __forceinline__ void run(float sq, float sig2, const double*, float& kv, float& base) { kv = base = sig2 * km_expf(-sq); }
 };
 template <> struct KmVal<double, PG_KIND_MATERN52> {
     static __device__ __forceinline__ void run(double sq, double sig2, const double* tab, double& kv, double& base) {
@@ -81,7 +86,7 @@ template <> struct KmVal<double, PG_KIND_MATERN52> {
 template <> struct KmVal<float, PG_KIND_MATERN52> {
     static __device__ __forceinline__ void run(float sq, float sig2, const double*, float& kv, float& base) {
         const float s5 = 2.2360679775f;
-        const float r = sqrtf(sq), e = sig2 * expf(-s5 * r);
+        const float r = km_sqrtf(sq), e = sig2 * km_expf(-s5 * r);
         base = (1.0f + s5 * r) * e;
         kv = base + (5.0f / 3.0f) * sq * e;
     }
