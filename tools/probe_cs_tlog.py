@@ -55,9 +55,12 @@ if clk:
 
 # one worker wave's slot beside the factor of micro-panel 3 (wave 1, slot of step jb = 2): from the barrier behind M to its start,
 # its tiles (deferred trailing update + the inverse's block row), its stores of the previous step's panel / block row
-print("worker slot (wave 1, step 2): starts %+.2f us after the barrier, tiles %.2f, stores %.2f; the factor beside it ends at %+.2f, the next barrier at %+.2f" % tuple(
-    np.median([v for v in col]) for col in zip(*[((tl[k][43] - tl[k][22]) / 100, (tl[k][46] - tl[k][43]) / 100, (tl[k][47] - tl[k][46]) / 100,
-                                                   (tl[k][38] - tl[k][22]) / 100, (tl[k][23] - tl[k][22]) / 100) for k in range(1, nblk - 1)])))
+ws = [((tl[k][43] - tl[k][22]) / 100, (tl[k][46] - tl[k][43]) / 100, (tl[k][38] - tl[k][22]) / 100, (tl[k][23] - tl[k][22]) / 100) for k in range(1, nblk - 1)]
+st = [(tl[k][47] - tl[k][46]) / 100 for k in range(1, nblk - 1) if tl[k][47] > tl[k][46]]     # stamp 47 is only written by leaf forms whose workers store (an unset stamp is 0)
+med = lambda v: float(np.median(v))
+print("worker slot (wave 1, step 2): starts %+.2f us after the barrier, tiles %.2f, stores %s; the factor beside it ends at %+.2f, the next barrier at %+.2f" % (
+    med([w[0] for w in ws]), med([w[1] for w in ws]), ("%.2f" % med(st)) if st else "not stamped (this leaf form's workers do not store in the slot)",
+    med([w[2] for w in ws]), med([w[3] for w in ws])))
 
 # the rows kernel of each step (its first critical workgroup): when it starts running relative to the leaf of the same step, and how long its
 # work BEFORE the leaf's flags takes (tile loads + the window's product): if start + pre-work exceeds the leaf's body, the step waits for the rows

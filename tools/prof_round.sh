@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-RD=${PG_ROUND:-r04}
+RD=${PG_ROUND:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$RD; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench.log 2>&1; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss -- python3 $R/tools/probe_eval_single_stream.py > $O/ss.log 2>&1; echo "ss rc=$?"
@@ -36,3 +36,15 @@ f=$(find $O/p8 -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_chai
 python3 $R/tools/probe_tri_rounds.py 8192 31 32 45 55 63 64 66 > $O/${RD}_tri_rounds_mixed.txt 2>&1; echo "rounds rc=$?"
 PG_GEMM_MIXED=0 python3 $R/tools/probe_tri_rounds.py 8192 31 32 45 55 63 64 66 > $O/${RD}_tri_rounds_plain.txt 2>&1; echo "rounds plain rc=$?"
 python3 $R/tools/probe_big_products.py 0 > $O/${RD}_big_products.txt 2>&1; echo "big products rc=$?"
+# round 5: the batched gradient path at config 4's dimension (D = 16: the matrix-pipe contraction), the batched diagonal prediction at the
+# reference's own test size (launches per prediction: the K = 4 run minus the fit-only run, over 5 predictions), the tile bodies alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/mle -- python3 $R/tools/probe_mle_batched.py 8 4096 16 4 > $O/mle.log 2>&1; echo "mle rc=$?"
+f=$(find $O/mle -name "*kernel_stats.csv" | head -1); python3 $R/tools/stats_summary.py $f > $O/${RD}_mle_nc8_n4096_kernel_stats.txt; tail -1 $O/mle.log >> $O/${RD}_mle_nc8_n4096_kernel_stats.txt; rm -rf $O/mle
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pr -- python3 $R/tools/probe_predict_batched.py 10 100 3 100 4 > $O/pr.log 2>&1; echo "predict rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pr0 -- python3 $R/tools/probe_predict_batched.py 10 100 3 100 0 > $O/pr0.log 2>&1; echo "predict fit-only rc=$?"
+PG_PREDICT_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prs -- python3 $R/tools/probe_predict_batched.py 10 100 3 100 4 > $O/prs.log 2>&1; echo "predict serial rc=$?"
+{ echo "# batched Exact_GP.predict(var=diag), 10 experts x 100 points, m = 100: 5 predictions (1 warm-up + 4) after one fit"; f=$(find $O/pr -name "*kernel_stats.csv" | head -1); python3 $R/tools/stats_summary.py $f; tail -1 $O/pr.log;
+  echo "# the fit alone (subtract)"; f=$(find $O/pr0 -name "*kernel_stats.csv" | head -1); python3 $R/tools/stats_summary.py $f;
+  echo "# PG_PREDICT_SERIAL=1: the experts one by one (rounds 1-4), same 5 predictions after one fit"; f=$(find $O/prs -name "*kernel_stats.csv" | head -1); python3 $R/tools/stats_summary.py $f; tail -1 $O/prs.log; } > $O/${RD}_predict_nc10_n100_kernel_stats.txt
+rm -rf $O/pr $O/pr0 $O/prs
+python3 $R/tools/probe_tile_bodies.py > $O/${RD}_tile_bodies.txt 2>&1; echo "tile bodies rc=$?"
