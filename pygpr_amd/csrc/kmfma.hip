@@ -235,7 +235,7 @@ template int pg_kbuild_mfma<float>(hipStream_t, const pg_covspec&, const double*
 // the sixteen columns of one).  Those two products accumulate in the matrix pipe's registers for the whole walk (their rows are the
 // wave's columns j); they, the column sums of G and the sigma / noise sums are folded once per workgroup into part[blk][nhp]
 // (entries in the `presc` convention of pg_grad_reduce_kernel: sums of (l_k D_k)^2 terms).
-template <typename T, int DP, int KIND>
+template <typename T, int DP, int KIND, bool GRIDX_COL = true>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kernel(pg_covspec spec, const double* __restrict__ hp, const T* __restrict__ X, long ldx, int n,
                                                            int d, const T* __restrict__ Kinv, long ldk, const T* __restrict__ alpha,
                                                            double* __restrict__ part, int nhp, GradBatch gb, int gch) {
@@ -244,9 +244,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kern
     constexpr int LDP = PT::LDP, NS = DP / 4;
     constexpr bool PACK = DP <= 8;
     X += blockIdx.z * gb.eX; hp += blockIdx.z * gb.ehp; Kinv += blockIdx.z * gb.eK; alpha += blockIdx.z * gb.ea; part += blockIdx.z * gb.epart;
-    const int tc = blockIdx.y, tiles = gridDim.y;
-    const int r_begin = tc + blockIdx.x * gch, r_end = min(r_begin + gch, tiles);
-    const int blk = tc * gridDim.x + blockIdx.x;
+    // grid.x = tile column (fastest), grid.y = which stretch of `gch` tile rows below its diagonal: the workgroups in flight together
+    // walk the SAME stretch of every tile column -- equally long walks, and K^-1 is read in whole row bands instead of sixteen 512-byte
+    // columns of every row at once.  N = 16384, fp64: D = 16 721 -> 437 us, D = 8 491 -> 309 us (PG_GRAD_GRID=0: the transposed mapping of the
+    // first version, tile column on grid.y; fp32 does not care: 1031 us both ways at n = 33792).
+    constexpr bool colfast = GRIDX_COL;
+    const int tc = colfast ? blockIdx.x : blockIdx.y, tiles = colfast ? gridDim.x : gridDim.y;
+    const int chunk = colfast ? blockIdx.y : blockIdx.x, nchunk = colfast ? gridDim.y : gridDim.x;
+    const int r_begin = tc + chunk * gch, r_end = min(r_begin + gch, tiles);
+    const int blk = tc * nchunk + chunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     for (int idx = tid; idx < nhp; idx += 256) part[(long)blk * nhp + idx] = 0.0;
     if (r_begin >= tiles) return;
@@ -328,6 +334,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kern
         const T* nb = nrs[cur];
         const T* ab = ars[cur];
         T accs_t = (T)0;                                             // this tile row's share of sum W K
+        typedef float pf2 __attribute__((ext_vector_type(2)));
+        pf2 acc2 = {0.0f, 0.0f}, pgs2 = {0.0f, 0.0f};                // (fp32 interior body: the same sums in pairs)
         // one tile row = four 16 x 16 blocks.  INTERIOR (strictly below the diagonal, inside the real points: weight 2 everywhere) is
         // a body without a single per-element test -- one basic block, so the four elements of a lane and the products of
         // neighbouring blocks interleave; the diagonal tile and a ragged last tile take the general body.
@@ -354,6 +362,36 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kern
 #pragma unroll
                 for (int s = 0; s < NS; ++s) acc = Mfma<T>::run(af[s], bq[s], acc);
                 T gr_[4];
+                if constexpr (sizeof(T) == 4 && INTERIOR) {
+                    // fp32, interior: the four elements of a lane as two PAIRS on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 /
+                    // v_pk_add_f32: two elements per issue slot); only the root and the exponential stay one element at a time
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        f2 sq = {(float)acc[r], (float)acc[r + 1]};
+                        sq = sq * -2.0f;
+                        const f2 ai2 = {(float)ai[r], (float)ai[r + 1]}, kin2 = {(float)kin[r], (float)kin[r + 1]};
+                        const f2 w = kin2 - ai2 * (float)aj;                       // (the weight 2 rides in sig2x2)
+                        f2 kv, base;
+                        if (KIND == PG_KIND_RBF) {
+                            const f2 t = sq * -1.44269504088896341f;
+                            const f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                            kv = base = e * (float)sig2x2;
+                        } else {
+                            sq = __builtin_elementwise_max(sq, (f2){0.0f, 0.0f});
+                            const f2 rr = {__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)};
+                            const f2 t = rr * (-2.2360679775f * 1.44269504088896341f);
+                            f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                            e = e * (float)sig2x2;
+                            base = rr * 2.2360679775f * e + e;
+                            kv = sq * (5.0f / 3.0f) * e + base;
+                        }
+                        const f2 gg = w * base;
+                        acc2 += w * kv;
+                        pgs2 += gg;
+                        gr_[r] = (T)gg.x; gr_[r + 1] = (T)gg.y;
+                    }
+                } else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     T sq = (T)-2 * acc[r];
@@ -391,7 +429,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kern
         };
         if (tr > tc && (tr + 1) * KT <= n) tile_row(std::true_type{});
         else tile_row(std::false_type{});
-        accs += (double)accs_t;
+        accs += (double)accs_t + (double)acc2.x + (double)acc2.y;
+        pgs += (T)(pgs2.x + pgs2.y);
         if (more) {
             prow.store(xr[cur ^ 1], sc, x0k, tid);
             if (tid < KT) ars[cur ^ 1][tid] = apf;
@@ -441,8 +480,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void pg_grad_mfma_kern
 template <typename T, int DP, int KIND>
 static int grad_mfma_launch(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, const T* Kinv, long ldk,
                             const T* alpha, double* part, int nhp, int tiles, const GradBatch& gb, int nexp, int gch) {
-    hipLaunchKernelGGL((pg_grad_mfma_kernel<T, DP, KIND>), dim3((tiles + gch - 1) / gch, tiles, nexp), dim3(256), 0, st, spec, hp, X, ldx, n, d,
-                       Kinv, ldk, alpha, part, nhp, gb, gch);
+    const int gridmode = getenv("PG_GRAD_GRID") ? atoi(getenv("PG_GRAD_GRID")) : 1;
+    if (gridmode)
+        hipLaunchKernelGGL((pg_grad_mfma_kernel<T, DP, KIND, true>), dim3(tiles, (tiles + gch - 1) / gch, nexp), dim3(256), 0, st, spec, hp, X, ldx, n,
+                           d, Kinv, ldk, alpha, part, nhp, gb, gch);
+    else
+        hipLaunchKernelGGL((pg_grad_mfma_kernel<T, DP, KIND, false>), dim3((tiles + gch - 1) / gch, tiles, nexp), dim3(256), 0, st, spec, hp, X, ldx, n,
+                           d, Kinv, ldk, alpha, part, nhp, gb, gch);
     PG_CHECK(hipGetLastError());
     return 0;
 }
@@ -451,8 +495,10 @@ static int grad_mfma_launch(hipStream_t st, const pg_covspec& spec, const double
 template <typename T>
 int pg_grad_mfma(hipStream_t st, const pg_covspec& spec, const double* hp, const T* X, long ldx, int n, int d, const T* Kinv, long ldk,
                  const T* alpha, double* part, int nhp, int tiles, const GradBatch& gb, int nexp, int* nblk) {
-    static const int gch_env = getenv("PG_GRAD_GCH") ? atoi(getenv("PG_GRAD_GCH")) : 16;   // 8 -> 16: 2-3 % (tools/probe_tile_bodies.py)
-    const int gch = std::max(1, std::min(gch_env, 64));
+    // tile rows per workgroup: a sixteenth of the tile column's length, 2 ... 32 (measured, us at gch = 2 / 4 / 8 / 16 / 32 / 64 -- N = 16384, D = 16, fp64:
+    // 562 / 481 / 444 / 437 / 467 / 567; n = 4096: 53 / 55 / 57 / 70 / 124 / 233; fp32 Matern n = 33792: 1419 / 1162 / 1060 / 1031 / 1004 / 1045)
+    const int gch_env = getenv("PG_GRAD_GCH") ? atoi(getenv("PG_GRAD_GCH")) : 0;
+    const int gch = gch_env > 0 ? std::min(gch_env, 64) : std::max(2, std::min(tiles / 16, 32));
     *nblk = tiles * ((tiles + gch - 1) / gch);
     const int kind = spec.kind[0];
 #define GR_GO(DP)                                                                                                                          \
