@@ -1605,6 +1605,15 @@ def test_matrix_pipe_bodies_on_uncentred_and_batched_data(ops, monkeypatch):
     xd_all = dev(x_all)
     ops.nlml_grad_batched(spec, dev(hp_all), xd_all, xd_all.stride(0), n, kinv_all, alpha_all, grad_all, ops.empty(nexp * ops.nlml_grad_worksize(n, hp.size)))
     assert np.array_equal(host(grad_all), np.stack(singles))
+    # (iii) the contraction's grid: tile column on grid.x (default: K^-1 read in whole row bands) against the first version's mapping, and
+    # every walk length -- the same partial sums in the same order, bit for bit
+    for grid, gch in (("0", "16"), ("1", "2"), ("1", "5"), ("0", "3"), ("1", "64")):
+        monkeypatch.setenv("PG_GRAD_GRID", grid)
+        monkeypatch.setenv("PG_GRAD_GCH", gch)
+        g2 = ops.zeros(nexp, hp.size)
+        ops.nlml_grad_batched(spec, dev(hp_all), xd_all, xd_all.stride(0), n, kinv_all, alpha_all, g2, ops.empty(nexp * ops.nlml_grad_worksize(n, hp.size)))
+        np.testing.assert_allclose(host(g2), host(grad_all), rtol=1e-13, atol=0)
+    monkeypatch.delenv("PG_GRAD_GRID"); monkeypatch.delenv("PG_GRAD_GCH")
 
 
 @pytest.mark.parametrize("variant_name", ["GEMM_NT", "GEMM_NT_64"])
