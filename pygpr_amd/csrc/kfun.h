@@ -61,9 +61,11 @@ __device__ __forceinline__ double pg_exp_tab(double x, const double* tab) {
 // sqrt(x) for x >= 0 in the Matern kernels' radial distance (a NaN stays a NaN): v_rsq_f64 refined by one Newton step on 1/sqrt and one on
 // the root itself (both quadratic: <= 1 ulp whatever the instruction's own precision) -- nine fp64 operations where the IEEE expansion
 // of sqrt() with its range scaling is about twenty.  Arguments below 1e-280 (a point against itself) return about 1e-140: every term
-// the kernels form from r then rounds exactly as with r = 0.
+// the kernels form from r then rounds exactly as with r = 0; arguments above 1e300 (points an overflow apart) are taken as 1e300 -- the
+// reciprocal root of infinity is 0 and would turn the result into a NaN where the covariance is simply 0.
 __device__ __forceinline__ double pg_sqrt_pos(double x) {
     x = (x < 1.0e-280) ? 1.0e-280 : x;
+    x = (x > 1.0e300) ? 1.0e300 : x;
     double y = __builtin_amdgcn_rsq(x);
     const double t = __builtin_fma(-0.5 * x * y, y, 0.5);
     y = __builtin_fma(y, t, y);
