@@ -98,6 +98,18 @@ def _stacked_rows(ts):
     return torch.as_strided(t0, (len(ts), t0.numel()), (step, 1))
 
 
+def _stacked_pair(a, b):
+    """a, b: [nc, m] views of the same shape and strides inside ONE allocation, b behind a: the [2, nc, m] view over both; else None."""
+    if a.shape != b.shape or a.stride() != b.stride() or a.dtype != b.dtype:
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return None
+    step = (b.data_ptr() - a.data_ptr()) // a.element_size()
+    if step <= 0 or step < (a.shape[0] - 1) * a.stride(0) + a.shape[1]:
+        return None
+    return torch.as_strided(a, (2,) + tuple(a.shape), (step,) + tuple(a.stride()))
+
+
 class GPR:
     """Base class for Gaussian process regression models (PyGPR/gpr.py:13-43)."""
 
@@ -446,8 +458,11 @@ class Exact_GP(GPR):
         # outputs: one fresh buffer per call, rows long enough for the padded last chunk -- the kernels write every chunk's means and
         # variances straight into their place (no staging copies: at the reference's test sizes those were half the call)
         mtot = ((m // _CHUNK) * _CHUNK + pad_to(m % _CHUNK)) if m % _CHUNK else m
-        mean_all = ops.empty(nb, mtot, dtype=self.dtype)
-        var_all = ops.empty(nb, mtot, dtype=self.dtype) if diag else None
+        # (means and variances as the two halves of ONE buffer: `predict` then brings both to the host in one transfer and one
+        # synchronisation -- at the reference's test sizes a device-to-host copy is a tenth of the call)
+        out_all = ops.empty(2 if diag else 1, nb, mtot, dtype=self.dtype)
+        mean_all = out_all[0]
+        var_all = out_all[1] if diag else None
         item = torch.empty(0, dtype=self.dtype).element_size()
         x_all = self._x_all
         for s in range(0, m, _CHUNK):
@@ -502,6 +517,12 @@ class Exact_GP(GPR):
         means, covs = self._predict_device(xpd, want)
         # (the batched prediction hands out rows of ONE fresh buffer: the stacked result is a view of it, no stacking kernel)
         mstack = _stacked_rows(means) if len(means) > 1 else None
+        if want == "diag" and self.batched and mstack is not None:
+            cstack = _stacked_rows(covs)
+            both = _stacked_pair(mstack, cstack) if cstack is not None else None
+            if both is not None:       # [2, nc, m] view of one buffer: one transfer
+                host = both.to(xp.device)
+                return [host[0].squeeze(), host[1]]
         ys = (mstack if mstack is not None else torch.stack(means)).squeeze().to(xp.device)   # squeeze_(): drops every size-1 dim (gpr.py:87)
         if want == "none":
             covars = NotImplemented
