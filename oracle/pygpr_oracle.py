@@ -310,6 +310,30 @@ def mle_loss_and_grad_lean(hp, x, y):
     return loss, g
 
 
+def matern52_nlml_lean(hp, x, y, rows=1024):
+    """NLML of Compose([Matern52, WN]) (MLE.loss, PyGPR/loss.py:35-57) at sizes where matern52_kernel's [n, n, d]
+    difference array does not fit (n = 33792: 146 GB): the same DIRECT squared differences, `rows` rows at a time (torch.cdist without the
+    matmul expansion, all intra-op threads), the same covariance formula, LAPACK potrf + a two-sided triangular solve.  Equal to
+    mle_loss([M52, WN], ...) to rounding (tests/test_oracle_golden.py); memory ~ 2 n^2 doubles."""
+    import torch
+
+    n, d = x.shape
+    sig, sn = float(hp[0]), float(hp[d + 1])
+    xl = torch.from_numpy(np.ascontiguousarray(x * hp[1:d + 1]))
+    yt = torch.from_numpy(np.ascontiguousarray(y))
+    k = torch.empty(n, n, dtype=torch.float64)
+    s5 = float(np.sqrt(5.0))
+    for r0 in range(0, n, rows):
+        r = torch.cdist(xl[r0:r0 + rows], xl, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+        e = torch.exp(-s5 * r)
+        k[r0:r0 + rows] = (sig * sig) * (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e
+    k.diagonal().add_(sn * sn + JITTER)
+    chol = torch.linalg.cholesky(k)
+    del k
+    alpha = torch.cholesky_solve(yt[:, None], chol)[:, 0]
+    return 0.5 * float(alpha @ yt) + float(torch.log(chol.diagonal()).sum()) + 0.5 * n * np.log(2.0 * np.pi)
+
+
 def mle_loss_and_grad_as_written(hp, x, y):
     """Second CPU baseline for bench.py (Compose([SE, WN]) only): the reference's algorithm AS WRITTEN, on its
     own substrate (torch CPU fp64): the dK stack [nhp,n,n] is materialised (covar.py:169-206, 247-269), and

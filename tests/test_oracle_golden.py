@@ -192,6 +192,16 @@ def test_matern52_unpinned_by_reference_matches_sklearn():
         np.testing.assert_allclose(dk[a], fd, atol=1e-8)
 
 
+def test_matern52_lean_nlml_is_the_oracles_nlml():
+    """`matern52_nlml_lean` (the full-size config-5 check of tests/test_parity_gpu.py evaluates it at n = 33792, where the [n, n, d]
+    difference array of `matern52_kernel` does not fit) is `mle_loss([M52, WN])` to rounding: row slabs that do and do not divide n."""
+    x, y = orc.synth(700, 16, seed=9)
+    hp = np.concatenate([[1.1], 0.3 + 0.4 * np.random.default_rng(2).random(16), [0.1]])
+    ref = orc.mle_loss([orc.M52, orc.WN], hp, x, y)
+    for rows in (128, 333, 1024):
+        np.testing.assert_allclose(orc.matern52_nlml_lean(hp, x, y, rows=rows), ref, rtol=1e-12)
+
+
 def test_as_written_torch_baseline_matches_solve_route():
     """bench.py's second CPU baseline (torch substrate) is the same function as the as-written oracle route."""
     rng = np.random.default_rng(5)
